@@ -1,0 +1,150 @@
+"""Synthetic inputs for tests and benchmarks (no dataset / checkpoint is available offline).
+
+* ``default_hparams``      -- the reference's shipped hyper-parameters
+                              (config/train_pointnet2_default.yaml:30-48, config/train_pipeline_default.yaml:39-74).
+* ``state_dict_spec``      -- (key, shape) list of the reference checkpoint schema, derived from
+                              the hyper-parameters only.
+* ``synthetic_state_dict`` -- seeded random weights; each tensor is drawn from its own generator keyed by the
+                              parameter NAME, so the values do not depend on module construction order.
+* ``synthetic_cloud``      -- seeded "dress" point clouds (open noisy cylinder) of SURVEY.md 8d.
+"""
+import copy
+import zlib
+
+import numpy as np
+import torch
+
+
+def default_hparams(grid=32, reduce_method="max", mc_surface=False):
+    hp = {
+        "pointnet2_params": dict(feature_dim=128, batch_norm=True, dropout=True, sa1_ratio=0.5, sa1_r=0.05,
+                                 sa2_ratio=0.25, sa2_r=0.1, fp3_k=1, fp2_k=3, fp1_k=3, symmetry_axis=None, nocs_bins=64),
+        "volume_agg_params": dict(nn_channels=[137, 137, 128], batch_norm=True, lower_corner=[0, 0, 0],
+                                  upper_corner=[1, 1, 1], grid_shape=[grid, grid, grid], reduce_method=reduce_method,
+                                  include_point_feature=True, include_confidence_feature=True),
+        "unet3d_params": dict(in_channels=128, out_channels=128, f_maps=32, layer_order="gcr", num_groups=8, num_levels=4),
+        "volume_decoder_params": dict(nn_channels=[128, 256, 256, 1], batch_norm=True),
+        "surface_decoder_params": dict(nn_channels=[128, 256, 256, 3], batch_norm=True),
+        "mc_surface_decoder_params": dict(nn_channels=[128, 256, 256, 1], batch_norm=True),
+        "mc_surface_loss_weight": 1 if mc_surface else 0,
+    }
+    return copy.deepcopy(hp)
+
+
+def _mlp_spec(prefix, channels, batch_norm=True):
+    out = []
+    for i in range(1, len(channels)):
+        p = f"{prefix}.{i - 1}"
+        out.append((p + ".0.weight", (channels[i], channels[i - 1])))
+        out.append((p + ".0.bias", (channels[i],)))
+        if batch_norm:
+            out += [(p + ".2.weight", (channels[i],)), (p + ".2.bias", (channels[i],)),
+                    (p + ".2.running_mean", (channels[i],)), (p + ".2.running_var", (channels[i],)),
+                    (p + ".2.num_batches_tracked", ())]
+    return out
+
+
+def unet_plan(in_channels, f_maps, num_levels):
+    """[(module prefix, conv1 (cin,cout), conv2 (cin,cout))] following components/unet3d.py:127-144,416-433."""
+    if isinstance(f_maps, int):
+        f_maps = [f_maps * 2 ** k for k in range(num_levels)]
+    plan = []
+    for i, fo in enumerate(f_maps):
+        cin = in_channels if i == 0 else f_maps[i - 1]
+        c1 = max(fo // 2, cin)
+        plan.append((f"encoders.{i}", (cin, c1), (c1, fo)))
+    rf = list(reversed(f_maps))
+    for i in range(len(rf) - 1):
+        plan.append((f"decoders.{i}", (rf[i] + rf[i + 1], rf[i + 1]), (rf[i + 1], rf[i + 1])))
+    return plan, f_maps
+
+
+def pointnet2_spec(p, prefix="pointnet2_nocs"):
+    bn = p.get("batch_norm", True)
+    fd = p["feature_dim"]
+    od = 3 if p.get("nocs_bins") is None else p["nocs_bins"] * 3
+    s = []
+    s += _mlp_spec(prefix + ".sa1_module.conv.local_nn", [6, 64, 64, 128], bn)
+    s += _mlp_spec(prefix + ".sa2_module.conv.local_nn", [131, 128, 128, 256], bn)
+    s += _mlp_spec(prefix + ".sa3_module.nn", [259, 256, 512, 1024], bn)
+    s += _mlp_spec(prefix + ".fp3_module.nn", [1280, 256, 256], bn)
+    s += _mlp_spec(prefix + ".fp2_module.nn", [384, 256, 128], bn)
+    s += _mlp_spec(prefix + ".fp1_module.nn", [131, 128, 128, 128], bn)
+    for name, (o, i) in (("lin1", (128, 128)), ("lin2", (fd, 128)), ("lin3", (od, fd)),
+                         ("global_lin1", (1024, 1024)), ("global_lin2", (od, 1024))):
+        s += [(f"{prefix}.{name}.weight", (o, i)), (f"{prefix}.{name}.bias", (o,))]
+    return s
+
+
+def state_dict_spec(hp):
+    s = pointnet2_spec(hp["pointnet2_params"])
+    va = hp["volume_agg_params"]
+    s += _mlp_spec("volume_agg.local_nn", va["nn_channels"], va.get("batch_norm", True))
+    u = hp["unet3d_params"]
+    plan, f_maps = unet_plan(u["in_channels"], u["f_maps"], u.get("num_levels", 4))
+    up = "unet_3d.abstract_3d_unet"
+    for mod, c1, c2 in plan:
+        for j, (ci, co) in ((1, c1), (2, c2)):
+            p = f"{up}.{mod}.basic_module.SingleConv{j}"
+            s += [(p + ".groupnorm.weight", (ci,)), (p + ".groupnorm.bias", (ci,)), (p + ".conv.weight", (co, ci, 3, 3, 3))]
+    s += [(up + ".final_conv.weight", (u["out_channels"], f_maps[0], 1, 1, 1)), (up + ".final_conv.bias", (u["out_channels"],))]
+    decs = [("volume_decoder", hp["volume_decoder_params"]), ("surface_decoder", hp["surface_decoder_params"])]
+    if hp.get("mc_surface_loss_weight", 0) > 0:
+        decs.append(("mc_surface_decoder", hp["mc_surface_decoder_params"]))
+    for name, dp in decs:
+        s += _mlp_spec(name + ".mlp", list(dp["nn_channels"]), dp.get("batch_norm", True))
+    return s
+
+
+def synthetic_tensor(key, shape, seed=0):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    if key.endswith("num_batches_tracked"):
+        return torch.tensor(1000, dtype=torch.int64)
+    if key.endswith("running_mean"):
+        return torch.randn(shape, generator=g) * 0.1
+    if key.endswith("running_var"):
+        return torch.rand(shape, generator=g) + 0.5
+    if key.endswith(".2.weight") or key.endswith("groupnorm.weight"):
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if key.endswith(".2.bias") or key.endswith("groupnorm.bias"):
+        return 0.1 * torch.randn(shape, generator=g)
+    if key.endswith("weight"):
+        fan_in = int(np.prod(shape[1:]))
+        bound = (3.0 / fan_in) ** 0.5  # unit-gain uniform: keeps activations O(1) through the stack
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+    if key.endswith("bias"):
+        return (torch.rand(shape, generator=g) * 2 - 1) * 0.1
+    raise KeyError(key)
+
+
+def synthetic_state_dict(hp, seed=0):
+    return {k: synthetic_tensor(k, shp, seed) for k, shp in state_dict_spec(hp)}
+
+
+def synthetic_cloud(num_garments, n_points=6000, seed=0):
+    """-> x (N,3) rgb in [0,1], pos (N,3) metres in the gripper frame, batch (N,) int64 sorted."""
+    xs, ps, bs = [], [], []
+    for b in range(num_garments):
+        rng = np.random.Generator(np.random.PCG64(seed * 1000003 + b))
+        while True:
+            th = rng.uniform(0, 2 * np.pi, n_points)
+            h = rng.uniform(0, 0.8, n_points)
+            r = 0.25 + 0.03 * np.sin(3 * th) + rng.normal(0, 0.005, n_points)
+            pos = np.stack([r * np.cos(th), r * np.sin(th), -h], axis=1).astype(np.float32)
+            if len(np.unique(pos, axis=0)) == n_points:
+                break
+        rgb = rng.uniform(0, 1, (n_points, 3)).astype(np.float32)
+        xs.append(rgb)
+        ps.append(pos)
+        bs.append(np.full(n_points, b, np.int64))
+    return (torch.from_numpy(np.concatenate(xs)), torch.from_numpy(np.concatenate(ps)), torch.from_numpy(np.concatenate(bs)))
+
+
+def shell_volume(Q):
+    """Analytic WNF-like shell used to benchmark / test the isosurface stage."""
+    ax = (np.arange(Q, dtype=np.float64) / (Q - 1))
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    rho = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2)
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    return (sig(80 * (0.3 - rho)) * sig(80 * (0.4 - np.abs(Z - 0.5)))).astype(np.float32)

@@ -1,0 +1,190 @@
+"""CPU: the oracle (oracle/) against the golden vectors produced by the reference's own modules
+(tests/golden/make_golden_ref.py) and by scikit-image 0.18.3 / scipy (tests/golden/make_golden_mc.py).
+This is what pins the oracle; the -m gpu tests then compare the HIP path with the pinned oracle."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from oracle import pipeline as P
+from garmentnets_amd import synthetic as S
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), np.uint8)
+
+
+# --------------------------------------------------------------------------------------------- MC33 / GGM
+def test_mc33_every_sign_pattern(golden_dir):
+    g = _load(golden_dir, "mc_golden.npz")
+    fo = vo = 0
+    for i, vol in enumerate(g["cell_vols"]):
+        nf, nv = int(g["cell_nf"][i]), int(g["cell_nv"][i])
+        v, f, n, a = O.marching_cubes_raw(vol, 0.0)
+        assert len(f) == nf and len(v) == nv, i
+        assert np.array_equal(f, g["cell_faces"][fo:fo + nf]), i
+        assert np.array_equal(v, g["cell_verts"][vo:vo + nv]), i
+        assert np.array_equal(a, g["cell_values"][vo:vo + nv]), i
+        np.testing.assert_allclose(n, g["cell_normals"][vo:vo + nv], atol=1e-6)
+        fo += nf
+        vo += nv
+
+
+def test_mc33_exact_level_corners(golden_dir):
+    g = _load(golden_dir, "mc_golden.npz")
+    fo = 0
+    for i, vol in enumerate(g["exact_vols"]):
+        nf = int(g["exact_nf"][i])
+        v, f, n, a = O.marching_cubes_raw(vol, 0.5)
+        assert len(f) == nf, i
+        assert np.array_equal(f, g["exact_faces"][fo:fo + nf]), i
+        fo += nf
+
+
+@pytest.mark.parametrize("name", ["noise14", "smooth24", "aniso", "exact12", "shell32"])
+def test_isosurface_volumes(golden_dir, name):
+    g = _load(golden_dir, "mc_golden.npz")
+    vol, level = g[name + "_vol"], float(g[name + "_level"])
+    Q = vol.shape[-1]
+    sp = 1 / (Q - 1)
+    v, f, n, a = O.marching_cubes(vol, level, (sp,) * 3, "ascent")
+    assert np.array_equal(f, g[name + "_faces"])           # bit-exact topology
+    assert v.dtype == np.float64 and np.array_equal(v, g[name + "_verts"])
+    assert np.array_equal(a, g[name + "_values"])
+    np.testing.assert_allclose(n, g[name + "_normals"], atol=1e-6)
+    ggm = O.ggm(vol, 0.5)
+    assert np.array_equal(ggm, g[name + "_ggm"])
+    assert np.array_equal(O.gather_nn(ggm, v, sp), g[name + "_verts_ggm"])
+
+
+def test_isosurface_shell128_checksums(golden_dir):
+    g = _load(golden_dir, "mc_golden.npz")
+    vol = S.shell_volume(128)
+    if not np.array_equal(_sha(vol), g["shell128_vol_sha"]):
+        pytest.skip("libm exp() differs from the golden generator's; volume not bit-identical")
+    v, f, n, a = O.marching_cubes(vol, 0.5, (1 / 127,) * 3)
+    assert len(v) == int(g["shell128_nv"]) and len(f) == int(g["shell128_nf"])
+    assert np.array_equal(_sha(f), g["shell128_faces_sha"])
+    assert np.array_equal(_sha(v.astype(np.float32)), g["shell128_verts_sha"])
+    assert np.array_equal(_sha(a), g["shell128_values_sha"])
+    assert np.array_equal(_sha(O.ggm(vol, 0.5)), g["shell128_ggm_sha"])
+    np.testing.assert_allclose(n[::97], g["shell128_normals_probe"], atol=1e-6)
+
+
+def test_mc_errors():
+    vol = np.zeros((4, 4, 4), np.float32)
+    with pytest.raises(ValueError):
+        O.marching_cubes(vol, 0.5)
+    vol[1, 1, 1] = 1.0
+    with pytest.raises(RuntimeError):   # level == max: inside test is strict '>', nothing is inside
+        O.marching_cubes(vol, 1.0)
+
+
+# --------------------------------------------------------------------------------------------- dense composition
+@pytest.mark.parametrize("name", ["small_max", "small_mean", "dress_g32"])
+def test_pipeline_against_reference_modules(golden_dir, name):
+    g = _load(golden_dir, f"ref_{name}.npz")
+    B, n, G, Q, seed, stride = [int(v) for v in g["meta"]]
+    hp = S.default_hparams(grid=G, reduce_method=str(g["reduce_method"]))
+    sd = S.synthetic_state_dict(hp, seed)
+    x, pos, batch = S.synthetic_cloud(B, n, seed)
+    tol = dict(rtol=0, atol=1e-5)
+    with torch.no_grad():
+        p2 = P.pointnet2_forward(sd, hp, x, pos, batch)
+        nd = p2["nocs_data"]
+        assert np.array_equal(nd["nocs_bin_idx"].numpy().astype(np.int8), g["nocs_bin_idx"])
+        np.testing.assert_allclose(p2["per_point_features"].numpy()[::stride], g["per_point_features"], **tol)
+        np.testing.assert_allclose(p2["per_point_logits"].numpy()[::stride], g["per_point_logits"], **tol)
+        np.testing.assert_allclose(nd["pred_confidence"].numpy()[::stride], g["pred_confidence"], **tol)
+        assert np.array_equal(nd["pos"].numpy()[::stride], g["pred_nocs"])
+        np.testing.assert_allclose(p2["global_logits"].numpy(), g["global_logits"], **tol)
+        np.testing.assert_allclose(p2["global_feature"].numpy(), g["global_feature"], **tol)
+        vin = P.volume_agg(sd, hp["volume_agg_params"], nd, B)
+        vol = P.unet3d(sd, hp["unet3d_params"], vin)
+        if "in_feature_volume" in g:
+            np.testing.assert_allclose(vin.numpy(), g["in_feature_volume"], **tol)
+            np.testing.assert_allclose(vol.numpy(), g["out_feature_volume"], **tol)
+        else:
+            np.testing.assert_allclose(vol.numpy()[:, ::16, ::3, ::3, ::3], g["out_volume_probe"], **tol)
+            np.testing.assert_allclose(vin.numpy()[:, ::16, ::3, ::3, ::3], g["in_volume_probe"], **tol)
+        np.testing.assert_allclose(vol.double().sum(dim=(2, 3, 4)).numpy(), g["out_volume_sum"], rtol=1e-6, atol=1e-3)
+        wnf = P.decode_volume(sd, vol[0:1], Q)
+        np.testing.assert_allclose(wnf.numpy(), g["wnf_volume"], **tol)
+        sq = torch.from_numpy(g["surf_query"])
+        np.testing.assert_allclose(P.implicit_decoder(sd, "surface_decoder", vol, sq).numpy(), g["surf_out"], **tol)
+        np.testing.assert_allclose(P.implicit_decoder(sd, "volume_decoder", vol, sq).numpy()[..., 0], g["volq_out"], **tol)
+
+
+@pytest.mark.parametrize("name", ["unet_g8", "unet_g16"])
+def test_unet_against_reference_module(golden_dir, name):
+    g = _load(golden_dir, f"ref_{name}.npz")
+    G, B, seed = [int(v) for v in g["meta"]]
+    hp = S.default_hparams(grid=G)
+    sd = S.synthetic_state_dict(hp, seed)
+    x = torch.randn(B, 128, G, G, G, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        y = P.unet3d(sd, hp["unet3d_params"], x)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+
+
+def test_gridding_luts(golden_dir):
+    g = _load(golden_dir, "ref_gridding.npz")
+    bins = torch.arange(64).unsqueeze(1).repeat(1, 3)
+    nocs = P.idxs_to_points(bins, [0, 0, 0], [1, 1, 1], (64,) * 3)
+    assert np.array_equal(nocs.numpy(), g["nocs_of_bin"])
+    for G in (8, 16, 32, 128):
+        ci = P.points_grid_idxs(nocs, [0, 0, 0], [1, 1, 1], (G,) * 3)
+        assert np.array_equal(ci.numpy(), g[f"cell_of_bin_{G}"])
+        assert np.array_equal(ci.numpy()[:, 0], (np.arange(64) * (G - 1)) // 63)
+        assert np.array_equal(P.idxs_to_points(ci, [0, 0, 0], [1, 1, 1], (G,) * 3).numpy(), g[f"corner_of_bin_{G}"])
+    pts = torch.from_numpy(g["rand_pts"])
+    idx = P.points_grid_idxs(pts, [0, 0, 0], [1, 1, 1], (32,) * 3)
+    assert np.array_equal(idx.numpy(), g["rand_idx"][:, 1:])
+    assert np.array_equal(P.grid_points(5).numpy(), g["grid_points_5"])
+
+
+# --------------------------------------------------------------------------------------------- unpinned ops: cross-checks
+def test_point_ops_against_plain_torch():
+    """torch_cluster / PyG are absent: cross-check the C restatements against independent dense torch formulations."""
+    x, pos, batch = S.synthetic_cloud(2, 400, seed=9)
+    ptr = O.batch_to_ptr(batch.numpy())
+    idx, optr = O.fps(pos.numpy(), ptr, 0.5)
+    assert list(optr) == [0, 200, 400]
+    # fps: greedy max-min property, per example
+    for b in range(2):
+        p = pos[ptr[b]:ptr[b + 1]]
+        sel = idx[optr[b]:optr[b + 1]] - ptr[b]
+        assert sel[0] == 0 and len(set(sel.tolist())) == len(sel)
+        d = torch.cdist(p.double(), p[sel].double())
+        for k in (1, 2, 17, 150):
+            dmin = d[:, :k].min(dim=1)[0]
+            assert abs(float(dmin.max()) - float(dmin[sel[k]])) < 1e-7
+    # ball query == first-64 of the ascending index list with d2 < r2
+    nbr, cnt = O.ball_query(pos.numpy(), ptr, idx, optr, 0.1, 16)
+    d2 = ((pos[idx].unsqueeze(1) - pos.unsqueeze(0)) ** 2).sum(-1)
+    same = batch[idx].unsqueeze(1) == batch.unsqueeze(0)
+    inside = (d2 < np.float32(0.1 * 0.1)) & same
+    for c in range(len(idx)):
+        exp = torch.nonzero(inside[c]).flatten()[:16].numpy()
+        assert cnt[c] == len(exp) and np.array_equal(nbr[c, :cnt[c]], exp) and np.all(nbr[c, cnt[c]:] == -1)
+    assert cnt.max() == 16 and cnt.min() < 16   # the cap is exercised
+    # knn interpolate vs topk formulation
+    feats = torch.randn(len(idx), 7)
+    y, kidx, kw = O.knn_interpolate(feats.numpy(), pos[idx].numpy(), optr, pos.numpy(), ptr, 3, return_knn=True)
+    d2q = ((pos.unsqueeze(1) - pos[idx].unsqueeze(0)) ** 2).sum(-1)
+    d2q = torch.where(batch.unsqueeze(1) == batch[idx].unsqueeze(0), d2q, torch.full_like(d2q, float("inf")))
+    tv, ti = torch.topk(d2q, 3, dim=1, largest=False)
+    assert np.array_equal(np.sort(kidx, 1), np.sort(ti.numpy(), 1))
+    w = 1.0 / torch.clamp(tv, min=1e-16)
+    ref = (feats[ti] * w.unsqueeze(-1)).sum(1) / w.sum(1, keepdim=True)
+    np.testing.assert_allclose(y, ref.numpy(), rtol=1e-5, atol=1e-6)
