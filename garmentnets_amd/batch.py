@@ -1,0 +1,41 @@
+"""Minimal stand-in for torch_geometric.data.Batch: attribute bag with ``num_graphs`` and ``.to()``.
+
+The reference builds ``Batch(x=, pos=, batch=, sim_points=, pred_confidence=)`` (networks/conv_implicit_wnf.py:232-237)
+and reads ``num_graphs`` (:51), which PyG derives as ``int(batch.max()) + 1`` (a device sync).  Here the per-example
+sizes can be attached once on the host (``sizes``) so that the hot path never synchronises.
+"""
+import torch
+
+
+class Batch:
+    def __init__(self, sizes=None, **kwargs):
+        self._sizes = None if sizes is None else [int(s) for s in sizes]
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith("_")]
+
+    @property
+    def sizes(self):
+        """points per example (host list); computed with ONE device sync if it was not provided."""
+        if self._sizes is None:
+            b = self.batch
+            n = int(b.max().item()) + 1 if b.numel() else 0
+            self._sizes = torch.bincount(b, minlength=n).cpu().tolist()
+        return self._sizes
+
+    @property
+    def num_graphs(self):
+        return len(self.sizes)
+
+    def to(self, device, **kw):
+        out = Batch(sizes=self._sizes)
+        for k in self.keys:
+            v = getattr(self, k)
+            setattr(out, k, v.to(device, **kw) if torch.is_tensor(v) else v)
+        return out
+
+    def __repr__(self):
+        return "Batch(" + ", ".join(f"{k}={tuple(getattr(self, k).shape) if torch.is_tensor(getattr(self, k)) else getattr(self, k)}" for k in self.keys) + ")"

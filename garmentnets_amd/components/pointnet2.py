@@ -1,0 +1,117 @@
+"""PointNet++ set-abstraction / feature-propagation modules on HIP kernels.
+
+API twin of /root/reference/components/pointnet2.py:11-76 (SAModule / GlobalSAModule / FPModule, attribute names
+``conv.local_nn`` / ``nn`` kept for checkpoint compatibility).  The third-party operators the reference calls
+(torch_cluster.fps / radius / knn, PyG PointConv / global_max_pool / knn_interpolate) are replaced by
+gn_fps, gn_ball_query, gn_sa_gather + gn_linear + gn_segment_max, gn_global_max_pool, gn_knn_interpolate.
+
+``batch`` arguments may be the reference's int64 batch vector or a ``Segments`` object (same information plus
+host-side sizes, so that no device synchronisation is needed on the hot path).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class Segments:
+    """Sorted batch vector in CSR form: host sizes, device int32 ptr, lazily materialised int64 batch vector."""
+
+    def __init__(self, sizes, device, batch=None):
+        self.sizes = [int(s) for s in sizes]
+        self.device = device
+        self.ptr = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes)]), dtype=torch.int32).to(device, non_blocking=True)
+        self._batch = batch
+
+    @staticmethod
+    def of(batch, sizes=None):
+        if isinstance(batch, Segments):
+            return batch
+        if sizes is None:
+            n = int(batch.max().item()) + 1 if batch.numel() else 0
+            sizes = torch.bincount(batch, minlength=n).cpu().tolist()
+        return Segments(sizes, batch.device, batch)
+
+    @property
+    def num(self):
+        return len(self.sizes)
+
+    @property
+    def total(self):
+        return int(sum(self.sizes))
+
+    @property
+    def batch(self):
+        if self._batch is None:
+            self._batch = torch.repeat_interleave(torch.arange(self.num, device=self.device),
+                                                  torch.tensor(self.sizes, device=self.device))
+        return self._batch
+
+
+class PointConv(torch.nn.Module):
+    """Parameter holder with PyG's attribute name (``local_nn``); evaluated by SAModule."""
+
+    def __init__(self, local_nn=None, global_nn=None, add_self_loops=True):
+        super().__init__()
+        self.local_nn = local_nn
+        self.global_nn = global_nn
+        self.add_self_loops = add_self_loops
+
+
+class SAModule(torch.nn.Module):
+    """fps -> ball query (<=64, first in index order) -> PointConv(local_nn, max) -- components/pointnet2.py:22-33."""
+
+    def __init__(self, ratio, r, nn):
+        super().__init__()
+        self.ratio = ratio
+        self.r = r
+        self.conv = PointConv(nn)
+
+    def forward(self, x, pos, batch):
+        seg = Segments.of(batch)
+        out_sizes = [ops.fps_count(n, self.ratio) for n in seg.sizes]
+        cseg = Segments(out_sizes, pos.device)
+        idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total)
+        nbr, _ = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
+        edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops)
+        h = self.conv.local_nn(edges)
+        out = ops.segment_max(h, slot_src, cseg.total, S)
+        self.last_graph = (idx, nbr)
+        return out, pos[idx.long()], cseg
+
+
+class GlobalSAModule(torch.nn.Module):
+    """MLP(cat[x, pos]) -> per-example max -- components/pointnet2.py:44-52."""
+
+    def __init__(self, nn):
+        super().__init__()
+        self.nn = nn
+
+    def forward(self, x, pos, batch):
+        seg = Segments.of(batch)
+        c = x.shape[1]
+        buf = ops.new_rows(x.shape[0], c + 3, x.device)
+        buf[:, :c] = x
+        buf[:, c:] = pos
+        h = self.nn(buf)
+        out = ops.global_max_pool(h, seg.ptr, seg.num)
+        return out, pos.new_zeros((seg.num, 3)), Segments([1] * seg.num, pos.device)
+
+
+class FPModule(torch.nn.Module):
+    """knn_interpolate -> cat skip -> MLP -- components/pointnet2.py:70-76."""
+
+    def __init__(self, k, nn):
+        super().__init__()
+        self.k = k
+        self.nn = nn
+
+    def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip):
+        seg, seg_skip = Segments.of(batch), Segments.of(batch_skip)
+        c = x.shape[1]
+        cs = 0 if x_skip is None else x_skip.shape[1]
+        buf = ops.new_rows(pos_skip.shape[0], c + cs, x.device)
+        ops.knn_interpolate(x, pos.contiguous(), seg.ptr, pos_skip.contiguous(), seg_skip.ptr, self.k, out=buf[:, :c])
+        if x_skip is not None:
+            buf[:, c:] = x_skip
+        return self.nn(buf), pos_skip, seg_skip

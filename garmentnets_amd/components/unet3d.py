@@ -1,0 +1,137 @@
+"""3-D UNet (GroupNorm -> Conv3d -> ReLU double convs, max-pool encoder, nearest-upsample + concat decoder) on HIP.
+
+Checkpoint-schema twin of the subset of /root/reference/components/unet3d.py that the pipeline instantiates
+(``Abstract3DUNet`` with ``basic_module=DoubleConv``, ``layer_order='gcr'``): module / parameter names
+``encoders.{i}.basic_module.SingleConv{1,2}.{groupnorm,conv}``, ``decoders.{i}...``, ``final_conv`` are kept.
+The torch layers only hold parameters.  Execution is channel-last ([B][D][H][W][C]):
+    GroupNorm  = gn_channel_stats (+ gn_groupnorm_affine)  -> per-(sample, channel) affine
+    conv+ReLU  = gn_conv3d_gcr: the affine is applied while the input halo is staged into LDS, the 3x3x3 conv runs as
+                 an implicit GEMM on fp32 MFMA; nearest upsampling and torch.cat((skip, x)) of the decoder
+                 (components/unet3d.py:291,330) are folded into the loader (second source read at half resolution)
+    MaxPool3d  = gn_maxpool3d_2,   final 1x1x1 conv = gn_linear.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .mlp import PackedModule, pack_wb
+
+
+def number_of_features_per_level(init_channel_number, num_levels):
+    return [init_channel_number * 2 ** k for k in range(num_levels)]
+
+
+class SingleConv(PackedModule, nn.Sequential):
+    """'gcr' block: GroupNorm(num_groups, Cin) -> Conv3d(Cin, Cout, 3, pad 1, no bias) -> ReLU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, order="gcr", num_groups=8, padding=1):
+        super().__init__()
+        if order != "gcr" or kernel_size != 3 or padding != 1:
+            raise NotImplementedError("garmentnets_amd implements the 'gcr' 3x3x3 SingleConv used by the GarmentNets pipeline")
+        groups = num_groups if in_channels >= num_groups else 1
+        assert in_channels % groups == 0
+        self.add_module("groupnorm", nn.GroupNorm(num_groups=groups, num_channels=in_channels))
+        self.add_module("conv", nn.Conv3d(in_channels, out_channels, 3, padding=1, bias=False))
+        self.add_module("ReLU", nn.ReLU(inplace=True))
+
+    def _pack(self):
+        w = self.conv.weight.detach().float()                      # (Cout, Cin, kd, kh, kw)
+        wp = w.permute(2, 3, 4, 1, 0).reshape(27, w.shape[1], w.shape[0]).contiguous()   # [tap][Cin][Cout]
+        return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
+
+    def run(self, src0, src1=None, stats0=None, stats1=None):
+        """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> [B][D][H][W][Cout]"""
+        wp, gamma, beta = self.packed()
+        st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
+        st1 = None
+        if src1 is not None:
+            st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
+        a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
+        return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True)
+
+
+class DoubleConv(nn.Sequential):
+    def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order="gcr", num_groups=8):
+        super().__init__()
+        if encoder:
+            c1_in, c1_out = in_channels, max(out_channels // 2, in_channels)
+            c2_in, c2_out = c1_out, out_channels
+        else:
+            c1_in, c1_out = in_channels, out_channels
+            c2_in, c2_out = out_channels, out_channels
+        self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
+        self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
+
+    def run(self, src0, src1=None):
+        return self.SingleConv2.run(self.SingleConv1.run(src0, src1))
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels, out_channels, apply_pooling=True, conv_layer_order="gcr", num_groups=8):
+        super().__init__()
+        self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
+        self.basic_module = DoubleConv(in_channels, out_channels, encoder=True, order=conv_layer_order, num_groups=num_groups)
+
+    def run(self, x):
+        if self.pooling is not None:
+            x = ops.maxpool3d_2(x)
+        return self.basic_module.run(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels, out_channels, conv_layer_order="gcr", num_groups=8):
+        super().__init__()
+        self.basic_module = DoubleConv(in_channels, out_channels, encoder=False, order=conv_layer_order, num_groups=num_groups)
+
+    def run(self, encoder_features, x):
+        # cat((encoder_features, upsample_nearest(x)), dim=channel) is never materialised
+        return self.basic_module.run(encoder_features, x)
+
+
+class FinalConv1x1(PackedModule, nn.Conv3d):
+    def _pack(self):
+        return pack_wb(self.weight.detach().reshape(self.out_channels, self.in_channels), self.bias)
+
+    def run(self, x):
+        wp, b, k = self.packed()
+        shp = x.shape
+        y = ops.linear(x.reshape(-1, shp[-1]), wp, b, None, None, relu=False, K=k)
+        return y.reshape(*shp[:-1], self.out_channels)
+
+
+class Abstract3DUNet(nn.Module):
+    def __init__(self, in_channels, out_channels, final_sigmoid=False, basic_module=DoubleConv, f_maps=64, layer_order="gcr",
+                 num_groups=8, num_levels=4, is_segmentation=False, testing=False, **kwargs):
+        super().__init__()
+        if basic_module is not DoubleConv or is_segmentation:
+            raise NotImplementedError("only the DoubleConv regression UNet of the GarmentNets pipeline is implemented")
+        if isinstance(f_maps, int):
+            f_maps = number_of_features_per_level(f_maps, num_levels=num_levels)
+        self.f_maps = list(f_maps)
+        self.encoders = nn.ModuleList([
+            Encoder(in_channels if i == 0 else f_maps[i - 1], f, apply_pooling=i > 0, conv_layer_order=layer_order, num_groups=num_groups)
+            for i, f in enumerate(f_maps)])
+        rf = list(reversed(f_maps))
+        self.decoders = nn.ModuleList([
+            Decoder(rf[i] + rf[i + 1], rf[i + 1], conv_layer_order=layer_order, num_groups=num_groups) for i in range(len(rf) - 1)])
+        self.final_conv = FinalConv1x1(f_maps[0], out_channels, 1)
+        self.final_activation = None
+
+    def run(self, x):
+        """channel-last in, channel-last out"""
+        feats = []
+        for enc in self.encoders:
+            x = enc.run(x)
+            feats.insert(0, x)
+        for dec, skip in zip(self.decoders, feats[1:]):
+            x = dec.run(skip, x)
+        return self.final_conv.run(x)
+
+    def forward(self, x):
+        """x: (B, C, D, H, W) as in the reference; returns (B, C', D, H, W) (a view over channel-last storage)."""
+        return self.run(to_channel_last(x)).permute(0, 4, 1, 2, 3)
+
+
+def to_channel_last(x):
+    """(B,C,D,H,W) tensor (any strides) -> contiguous [B][D][H][W][C]; free when x already is a channel-last view."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()

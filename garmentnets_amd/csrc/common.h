@@ -1,0 +1,52 @@
+// common.h -- shared helpers for the gfx950 kernels of libgarmentnets_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/garmentnets_hip.h"
+
+#define GN_WAVE 64
+
+void gn_set_error(const char *fmt, ...);
+
+#define GN_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            gn_set_error(__VA_ARGS__);   \
+            return GN_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define GN_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            gn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return GN_ELAUNCH;                                                       \
+        }                                                                            \
+    } while (0)
+
+#define GN_HIP(call, name)                                                           \
+    do {                                                                             \
+        hipError_t e__ = (call);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            gn_set_error("%s: %s", name, hipGetErrorString(e__));                    \
+            return GN_ELAUNCH;                                                       \
+        }                                                                            \
+    } while (0)
+
+static inline hipStream_t gn_stream(void *s) { return (hipStream_t)s; }
+static inline int64_t gn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// squared distance in the pinned operation order ((dx*dx + dy*dy) + dz*dz), fp32, no FMA contraction
+// (the library is compiled with -ffp-contract=off; the intrinsics make it explicit).
+__device__ __forceinline__ float gn_sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    float s = __fmul_rn(dx, dx);
+    s = __fadd_rn(s, __fmul_rn(dy, dy));
+    s = __fadd_rn(s, __fmul_rn(dz, dz));
+    return s;
+}
+
+__device__ __forceinline__ int gn_lane() { return threadIdx.x & 63; }

@@ -1,0 +1,130 @@
+// grid.hip -- VolumeFeatureAggregator: per-point cell index + aggregation features, scatter (max | mean) into a
+// channel-last feature volume.  Reference: /root/reference/networks/conv_implicit_wnf.py:43-100,
+// components/gridding.py:161-256 (VirtualGrid index maths, fp32, truncation toward zero).
+#include "common.h"
+
+struct GridParams {
+    float lower[3], upper[3];
+    int grid[3];
+};
+
+// one wavefront per point
+__global__ __launch_bounds__(256) void grid_features_kernel(const float *__restrict__ feat, int ldf, int Cf,
+                                                            const float *__restrict__ nocs, const float *__restrict__ sim_pos,
+                                                            const float *__restrict__ conf, const int64_t *__restrict__ batch,
+                                                            int64_t N, GridParams gp, int include_point, int include_conf,
+                                                            float *__restrict__ out, int ldo, int32_t *__restrict__ flat_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= N) return;
+    float *o = out + p * ldo;
+    for (int t = lane; t < Cf; t += 64) o[t] = feat[p * ldf + t];
+    // gridding.py:161-186: idx_f = (p + (-lc)) * ((shape-1)/(uc-lc)); idx = clamp(trunc(idx_f), 0, shape-1)
+    int cell[3];
+    float corner[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lc = gp.lower[a], uc = gp.upper[a];
+        float idx_scale = __fsub_rn((float)gp.grid[a], 1.0f);
+        float scales = __fdiv_rn(idx_scale, __fsub_rn(uc, lc));
+        float f = __fmul_rn(__fadd_rn(nocs[p * 3 + a], -lc), scales);
+        long long i = (long long)f;  // truncation toward zero (v_cvt, saturating)
+        if (i < 0) i = 0;
+        if (i > gp.grid[a] - 1) i = gp.grid[a] - 1;
+        cell[a] = (int)i;
+        // gridding.py:230-256: corner = idx * ((uc-lc)/(shape-1)) + lc
+        float inv = __fdiv_rn(__fsub_rn(uc, lc), idx_scale);
+        corner[a] = __fadd_rn(__fmul_rn((float)cell[a], inv), lc);
+    }
+    if (lane == 0) {
+        long long b = batch[p];
+        flat_idx[p] = (int32_t)((((b * gp.grid[0] + cell[0]) * gp.grid[1] + cell[1]) * (long long)gp.grid[2]) + cell[2]);
+    }
+    int c = Cf;
+    if (include_point) {
+        if (lane < 3) o[c + lane] = __fsub_rn(nocs[p * 3 + lane], corner[lane]);
+        else if (lane < 6) o[c + lane] = sim_pos[p * 3 + lane - 3];
+        c += 6;
+    }
+    if (include_conf && lane < 3) o[c + lane] = conf[p * 3 + lane];
+}
+
+extern "C" int gn_grid_features(const float *feat, int ldf, int Cf, const float *nocs, const float *sim_pos, const float *conf,
+                                const int64_t *batch, int64_t N, const float lower[3], const float upper[3], const int grid[3],
+                                int include_point, int include_conf, float *out, int ldo, int32_t *flat_idx, void *stream) {
+    const int Ctot = Cf + (include_point ? 6 : 0) + (include_conf ? 3 : 0);
+    GN_REQUIRE(N >= 0 && Cf >= 0 && ldo >= Ctot, "gn_grid_features: bad sizes");
+    if (N == 0) return GN_OK;
+    GridParams gp;
+    for (int a = 0; a < 3; ++a) { gp.lower[a] = lower[a]; gp.upper[a] = upper[a]; gp.grid[a] = grid[a]; }
+    hipLaunchKernelGGL(grid_features_kernel, dim3((unsigned)gn_cdiv(N, 4)), dim3(256), 0, gn_stream(stream), feat, ldf, Cf, nocs,
+                       sim_pos, conf, batch, N, gp, include_point, include_conf, out, ldo, flat_idx);
+    GN_LAUNCH_CHECK("gn_grid_features");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ scatter
+// order-preserving float <-> uint encoding: enc(x) is monotone in x and > 0 for every non-NaN float, so a
+// zero-filled volume reads as "empty" and atomicMax on the encoding is an order-independent float max.
+__device__ __forceinline__ unsigned enc_f32(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(unsigned e) {
+    unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(u);
+}
+
+template <int REDUCE>  // 0 max, 1 mean
+__global__ __launch_bounds__(256) void scatter_accum_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ flat_idx,
+                                                            int64_t N, int C, float *__restrict__ vol, int32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= N) return;
+    const int64_t cell = flat_idx[p];
+    if (lane == 0) atomicAdd(&count[cell], 1);
+    float *v = vol + cell * C;
+    for (int ch = lane; ch < C; ch += 64) {
+        float x = src[p * lds + ch];
+        if (REDUCE == 0) atomicMax(reinterpret_cast<unsigned *>(v) + ch, enc_f32(x));
+        else atomicAdd(v + ch, x);
+    }
+}
+
+// the first point that reaches a cell here finalises it (decode the max / divide the sum by the count)
+template <int REDUCE>
+__global__ __launch_bounds__(256) void scatter_finalize_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int C,
+                                                               float *__restrict__ vol, int32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= N) return;
+    const int64_t cell = flat_idx[p];
+    int c = 0;
+    if (lane == 0) c = atomicExch(&count[cell], 0);
+    c = __shfl(c, 0);
+    if (c <= 0) return;
+    float *v = vol + cell * C;
+    for (int ch = lane; ch < C; ch += 64) {
+        if (REDUCE == 0) v[ch] = dec_f32(__float_as_uint(v[ch]));
+        else v[ch] = __fdiv_rn(v[ch], (float)c);
+    }
+}
+
+extern "C" int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
+                               float *vol, int32_t *count_ws, void *stream) {
+    GN_REQUIRE(N >= 0 && C > 0 && cells >= 0 && (reduce == 0 || reduce == 1), "gn_grid_scatter: bad arguments");
+    hipStream_t st = gn_stream(stream);
+    GN_HIP(hipMemsetAsync(vol, 0, sizeof(float) * (size_t)cells * C, st), "gn_grid_scatter(memset vol)");
+    GN_HIP(hipMemsetAsync(count_ws, 0, sizeof(int32_t) * (size_t)cells, st), "gn_grid_scatter(memset count)");
+    if (N == 0) return GN_OK;
+    dim3 grid((unsigned)gn_cdiv(N, 4)), block(256);
+    if (reduce == 0) {
+        hipLaunchKernelGGL(scatter_accum_kernel<0>, grid, block, 0, st, src, lds, flat_idx, N, C, vol, count_ws);
+        hipLaunchKernelGGL(scatter_finalize_kernel<0>, grid, block, 0, st, flat_idx, N, C, vol, count_ws);
+    } else {
+        hipLaunchKernelGGL(scatter_accum_kernel<1>, grid, block, 0, st, src, lds, flat_idx, N, C, vol, count_ws);
+        hipLaunchKernelGGL(scatter_finalize_kernel<1>, grid, block, 0, st, flat_idx, N, C, vol, count_ws);
+    }
+    GN_LAUNCH_CHECK("gn_grid_scatter");
+    return GN_OK;
+}

@@ -1,0 +1,743 @@
+// iso.hip -- isosurface stage on gfx950: Gaussian gradient magnitude, min/max, Lewiner marching cubes (MC33),
+// nearest-voxel gather.  Replaces scipy.ndimage.gaussian_gradient_magnitude + skimage.measure.marching_cubes
+// (method='lewiner') + the vertex look-ups of /root/reference/predict.py:160-181.
+//
+// MC33 is formulated for the GPU as classify -> scan -> emit instead of scikit-image's sequential sweep:
+//   classify : one thread per cell: sign index, Lewiner case, face / interior tests -> tiling row + #triangles,
+//              and the number of vertices this cell is the FIRST user of in sweep order (axis0 outer, axis2 inner):
+//              an edge is new for a cell iff no lexicographically earlier cell shares it, which depends only on the
+//              edge's position in the cell and on the cell touching the low boundary; the centre vertex is always new.
+//   scan     : exclusive prefix sums of (new vertices, triangles) over cells in sweep order
+//              => vertex ids = order of first use, faces in sweep order, exactly as the sequential algorithm.
+//   emit     : owners write vertex positions + the global edge->vertex table; every cell writes its faces;
+//              a per-vertex gather over the (<=4) adjacent cells, visited in sweep order, accumulates the normal
+//              contributions in the same order as the sequential algorithm and the max cell span ("values").
+// The look-up tables (13.4 KB, Lewiner et al. 2003) are staged into LDS by every workgroup.
+#include "common.h"
+#include "mc33_luts.h"
+
+#include <float.h>
+
+// ================================================================================================ GGM
+struct GgmWeights {
+    double w[65];
+    int radius;
+    int symmetric;  // 1 symmetric, -1 antisymmetric, 0 generic
+};
+
+// correlate1d along `axis`, edge-replicate, fp64 accumulation in scipy's operation order, fp32 store
+__global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1,
+                                                            int n2, int axis, GgmWeights gw) {
+    const int64_t tot = (int64_t)n0 * n1 * n2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tot) return;
+    const int i2 = (int)(t % n2), i1 = (int)((t / n2) % n1), i0 = (int)(t / ((int64_t)n1 * n2));
+    const int n = axis == 0 ? n0 : (axis == 1 ? n1 : n2);
+    const int64_t st = axis == 0 ? (int64_t)n1 * n2 : (axis == 1 ? n2 : 1);
+    const int i = axis == 0 ? i0 : (axis == 1 ? i1 : i2);
+    const int64_t base = t - (int64_t)i * st;
+    const int r = gw.radius;
+    auto at = [&](int j) -> double {
+        int k = i + j;
+        k = k < 0 ? 0 : (k >= n ? n - 1 : k);
+        return (double)in[base + (int64_t)k * st];
+    };
+    double acc;
+    if (gw.symmetric == 1) {
+        acc = __dmul_rn(at(0), gw.w[r]);
+        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(at(j), at(-j)), gw.w[r + j]));
+    } else if (gw.symmetric == -1) {
+        acc = __dmul_rn(at(0), gw.w[r]);
+        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dsub_rn(at(j), at(-j)), gw.w[r + j]));
+    } else {
+        acc = 0.0;
+        for (int j = -r; j <= r; ++j) acc = __dadd_rn(acc, __dmul_rn(at(j), gw.w[r + j]));
+    }
+    out[t] = (float)acc;
+}
+
+// out = (first ? 0 : out) + t*t ; last: out = sqrt(out)
+__global__ __launch_bounds__(256) void ggm_accum_kernel(const float *__restrict__ t, float *__restrict__ out, int64_t tot, int first,
+                                                        int last) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    float sq = __fmul_rn(t[i], t[i]);
+    float v = first ? sq : __fadd_rn(out[i], sq);
+    // correctly rounded fp32 sqrt (numpy.sqrt): fp64 sqrt of an fp32 value rounds to the same fp32 result
+    out[i] = last ? (float)__dsqrt_rn((double)v) : v;
+}
+
+static void ggm_kernel1d(double sigma, int order, int radius, GgmWeights &g) {
+    // scipy _gaussian_kernel1d + the [::-1] of gaussian_filter1d
+    const double sigma2 = sigma * sigma;
+    const int n = 2 * radius + 1;
+    double phi[65], sum = 0.0;
+    for (int i = 0; i < n; ++i) { double x = (double)(i - radius); phi[i] = exp(-0.5 / sigma2 * x * x); sum += phi[i]; }
+    for (int i = 0; i < n; ++i) phi[i] /= sum;
+    for (int i = 0; i < n; ++i) {
+        double x = (double)(i - radius);
+        g.w[n - 1 - i] = order == 1 ? (-x / sigma2) * phi[i] : phi[i];
+    }
+    g.radius = radius;
+    int sym = 1, anti = 1;
+    for (int j = 1; j <= radius; ++j) {
+        if (fabs(g.w[radius + j] - g.w[radius - j]) > DBL_EPSILON) sym = 0;
+        if (fabs(g.w[radius + j] + g.w[radius - j]) > DBL_EPSILON) anti = 0;
+    }
+    g.symmetric = sym ? 1 : (anti ? -1 : 0);
+}
+
+extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
+    GN_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
+    const int radius = (int)(4.0 * sigma + 0.5);
+    GN_REQUIRE(radius >= 1 && radius <= 32, "gn_ggm3d: unsupported sigma");
+    GgmWeights w0, w1;
+    ggm_kernel1d(sigma, 0, radius, w0);
+    ggm_kernel1d(sigma, 1, radius, w1);
+    const int64_t tot = (int64_t)n0 * n1 * n2;
+    float *t1 = tmp, *t2 = tmp + tot;
+    hipStream_t st = gn_stream(stream);
+    dim3 grid((unsigned)gn_cdiv(tot, 256)), block(256);
+    for (int axis = 0; axis < 3; ++axis) {
+        const float *src = vol;
+        float *dst = t1;
+        for (int a = 0; a < 3; ++a) {
+            hipLaunchKernelGGL(ggm_correlate_kernel, grid, block, 0, st, src, dst, n0, n1, n2, a, a == axis ? w1 : w0);
+            src = dst;
+            dst = (dst == t1) ? t2 : t1;
+        }
+        hipLaunchKernelGGL(ggm_accum_kernel, grid, block, 0, st, src, out, tot, axis == 0, axis == 2);
+    }
+    GN_LAUNCH_CHECK("gn_ggm3d");
+    return GN_OK;
+}
+
+// ================================================================================================ min / max
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out_enc) {
+    float mn = 3.4e38f, mx = -3.4e38f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // order-preserving encodings so that integer atomics implement float min / max
+        unsigned emn = __float_as_uint(mn), emx = __float_as_uint(mx);
+        emn = (emn & 0x80000000u) ? ~emn : (emn | 0x80000000u);
+        emx = (emx & 0x80000000u) ? ~emx : (emx | 0x80000000u);
+        atomicMin(&out_enc[0], emn);
+        atomicMax(&out_enc[1], emx);
+    }
+}
+__global__ void minmax_init_kernel(unsigned *o) { o[0] = 0xffffffffu; o[1] = 0u; }
+__global__ void minmax_decode_kernel(unsigned *o) {
+    for (int k = 0; k < 2; ++k) {
+        unsigned e = o[k];
+        unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+        o[k] = u;
+    }
+}
+
+extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) {
+    GN_REQUIRE(n > 0, "gn_minmax: empty input");
+    hipStream_t st = gn_stream(stream);
+    unsigned *o = reinterpret_cast<unsigned *>(out2);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, o);
+    int blocks = (int)(gn_cdiv(n, 256) < 2048 ? gn_cdiv(n, 256) : 2048);
+    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, st, x, n, o);
+    hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, st, o);
+    GN_LAUNCH_CHECK("gn_minmax");
+    return GN_OK;
+}
+
+// ================================================================================================ MC33
+__device__ const int8_t MC_LUT_G[MC_LUT_BYTES] = MC_LUT_INITIALIZER;
+
+__device__ __forceinline__ void mc_stage_lut(int8_t *lut) {
+    const int4 *src = reinterpret_cast<const int4 *>(MC_LUT_G);
+    int4 *dst = reinterpret_cast<int4 *>(lut);
+    for (int i = threadIdx.x; i < MC_LUT_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+struct McDims {
+    int n0, n1, n2;   // volume (axis0 = z, axis1 = y, axis2 = x)
+    int c0, c1, c2;   // cells
+    int64_t ncells, nvox;
+};
+
+// corner values minus level, Lewiner numbering: v0=(0,0,0) v1=(x+1) v2=(x+1,y+1) v3=(y+1) v4..v7 at z+1
+__device__ __forceinline__ void mc_load_cell(const float *__restrict__ vol, const McDims &d, int x, int y, int z, double level,
+                                             double v[8]) {
+    const float *p = vol + ((int64_t)z * d.n1 + y) * d.n2 + x;
+    const int64_t sy = d.n2, sz = (int64_t)d.n1 * d.n2;
+    v[0] = (double)p[0] - level;
+    v[1] = (double)p[1] - level;
+    v[2] = (double)p[sy + 1] - level;
+    v[3] = (double)p[sy] - level;
+    v[4] = (double)p[sz] - level;
+    v[5] = (double)p[sz + 1] - level;
+    v[6] = (double)p[sz + sy + 1] - level;
+    v[7] = (double)p[sz + sy] - level;
+}
+
+__device__ __forceinline__ bool mc_face_test(const double *v, int face) {
+    // corners (A,B,C,D) of face |f|, packed 3 bits each
+    const unsigned packed[7] = {0u, 0u | (4u << 3) | (5u << 6) | (1u << 9), 1u | (5u << 3) | (6u << 6) | (2u << 9),
+                                2u | (6u << 3) | (7u << 6) | (3u << 9), 3u | (7u << 3) | (4u << 6) | (0u << 9),
+                                0u | (3u << 3) | (2u << 6) | (1u << 9), 4u | (7u << 3) | (6u << 6) | (5u << 9)};
+    const int af = face < 0 ? -face : face;
+    const unsigned pk = packed[af];
+    const double A = v[pk & 7], B = v[(pk >> 3) & 7], C = v[(pk >> 6) & 7], D = v[(pk >> 9) & 7];
+    const double x = __dsub_rn(__dmul_rn(A, C), __dmul_rn(B, D));
+    if (x > -DBL_EPSILON && x < DBL_EPSILON) return face >= 0;
+    return __dmul_rn(__dmul_rn((double)face, A), x) >= 0;
+}
+
+__device__ __forceinline__ bool mc_interior_test(const int8_t *lut, const double *v, int cas, int cfg, int sub, int s) {
+    double At, Bt, Ct, Dt;
+    if (cas == 4 || cas == 10) {
+        const double e40 = __dsub_rn(v[4], v[0]), e62 = __dsub_rn(v[6], v[2]), e73 = __dsub_rn(v[7], v[3]), e51 = __dsub_rn(v[5], v[1]);
+        const double a = __dsub_rn(__dmul_rn(e40, e62), __dmul_rn(e73, e51));
+        double b = __dadd_rn(__dmul_rn(v[2], e40), __dmul_rn(v[0], e62));
+        b = __dsub_rn(b, __dmul_rn(v[1], e73));
+        b = __dsub_rn(b, __dmul_rn(v[3], e51));
+        const double t = __ddiv_rn(-b, __dadd_rn(__dmul_rn(2.0, a), DBL_EPSILON));
+        if (t < 0 || t > 1) return s > 0;
+        At = __dadd_rn(v[0], __dmul_rn(e40, t));
+        Bt = __dadd_rn(v[3], __dmul_rn(e73, t));
+        Ct = __dadd_rn(v[2], __dmul_rn(e62, t));
+        Dt = __dadd_rn(v[1], __dmul_rn(e51, t));
+    } else {
+        int edge = -1;
+        if (cas == 6) edge = lut[MC_OFF_TEST6 + cfg * 3 + 2];
+        else if (cas == 7) edge = lut[MC_OFF_TEST7 + cfg * 5 + 4];
+        else if (cas == 12) edge = lut[MC_OFF_TEST12 + cfg * 4 + 3];
+        else if (cas == 13) edge = lut[MC_OFF_TILING13_5_1 + (cfg * 4 + sub) * 18];
+        if (edge < 0 || edge > 11) return s < 0;
+        // reference edge (p,q) followed by the three edges parallel to it
+        const signed char T[12][8] = {{0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
+                                      {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2}, {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0},
+                                      {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
+        const signed char *e = T[edge];
+        const double t = __ddiv_rn(v[e[0]], __dadd_rn(__dsub_rn(v[e[0]], v[e[1]]), DBL_EPSILON));
+        At = 0;
+        Bt = __dadd_rn(v[e[2]], __dmul_rn(__dsub_rn(v[e[3]], v[e[2]]), t));
+        Ct = __dadd_rn(v[e[4]], __dmul_rn(__dsub_rn(v[e[5]], v[e[4]]), t));
+        Dt = __dadd_rn(v[e[6]], __dmul_rn(__dsub_rn(v[e[7]], v[e[6]]), t));
+    }
+    int test = 0;
+    if (At >= 0) test += 1;
+    if (Bt >= 0) test += 2;
+    if (Ct >= 0) test += 4;
+    if (Dt >= 0) test += 8;
+    const double sad = __dsub_rn(__dmul_rn(At, Ct), __dmul_rn(Bt, Dt));
+    switch (test) {
+        case 5: return (sad < DBL_EPSILON) ? (s > 0) : false;    // pinned scikit-image behaviour (see oracle)
+        case 10: return (sad >= DBL_EPSILON) ? (s > 0) : false;
+        case 7: case 11: case 13: case 14: case 15: return s < 0;
+        default: return s > 0;
+    }
+}
+
+// -> LUT offset of the tiling row (or -1) and number of triangles
+__device__ __forceinline__ int mc_resolve(const int8_t *lut, const double *v, int index, int &ntri) {
+    const int cas = lut[MC_OFF_CASES + index * 2], cfg = lut[MC_OFF_CASES + index * 2 + 1];
+#define R2(T, n) { ntri = (n); return MC_OFF_##T + cfg * MC_DIM1_##T; }
+#define R3(T, j, n) { ntri = (n); return MC_OFF_##T + (cfg * MC_DIM1_##T + (j)) * MC_DIM2_##T; }
+    int sub = 0;
+    switch (cas) {
+        case 1: R2(TILING1, 1)
+        case 2: R2(TILING2, 2)
+        case 3:
+            if (mc_face_test(v, lut[MC_OFF_TEST3 + cfg])) R2(TILING3_2, 4)
+            R2(TILING3_1, 2)
+        case 4:
+            if (mc_interior_test(lut, v, cas, cfg, 0, lut[MC_OFF_TEST4 + cfg])) R2(TILING4_1, 2)
+            R2(TILING4_2, 6)
+        case 5: R2(TILING5, 3)
+        case 6:
+            if (mc_face_test(v, lut[MC_OFF_TEST6 + cfg * 3])) R2(TILING6_2, 5)
+            if (mc_interior_test(lut, v, cas, cfg, 0, lut[MC_OFF_TEST6 + cfg * 3 + 1])) R2(TILING6_1_1, 3)
+            R2(TILING6_1_2, 9)
+        case 7:
+            for (int i = 0; i < 3; ++i)
+                if (mc_face_test(v, lut[MC_OFF_TEST7 + cfg * 5 + i])) sub |= 1 << i;
+            switch (sub) {
+                case 0: R2(TILING7_1, 3)
+                case 1: R3(TILING7_2, 0, 5)
+                case 2: R3(TILING7_2, 1, 5)
+                case 3: R3(TILING7_3, 0, 9)
+                case 4: R3(TILING7_2, 2, 5)
+                case 5: R3(TILING7_3, 1, 9)
+                case 6: R3(TILING7_3, 2, 9)
+                default:
+                    if (mc_interior_test(lut, v, cas, cfg, 0, lut[MC_OFF_TEST7 + cfg * 5 + 3])) R2(TILING7_4_2, 9)
+                    R2(TILING7_4_1, 5)
+            }
+        case 8: R2(TILING8, 2)
+        case 9: R2(TILING9, 4)
+        case 10: {
+            const bool f0 = mc_face_test(v, lut[MC_OFF_TEST10 + cfg * 3]), f1 = mc_face_test(v, lut[MC_OFF_TEST10 + cfg * 3 + 1]);
+            if (f0 && f1) R2(TILING10_1_1_, 4)
+            if (f0) R2(TILING10_2, 8)
+            if (f1) R2(TILING10_2_, 8)
+            if (mc_interior_test(lut, v, cas, cfg, 0, lut[MC_OFF_TEST10 + cfg * 3 + 2])) R2(TILING10_1_1, 4)
+            R2(TILING10_1_2, 8)
+        }
+        case 11: R2(TILING11, 4)
+        case 12: {
+            const bool f0 = mc_face_test(v, lut[MC_OFF_TEST12 + cfg * 4]), f1 = mc_face_test(v, lut[MC_OFF_TEST12 + cfg * 4 + 1]);
+            if (f0 && f1) R2(TILING12_1_1_, 4)
+            if (f0) R2(TILING12_2, 8)
+            if (f1) R2(TILING12_2_, 8)
+            if (mc_interior_test(lut, v, cas, cfg, 0, lut[MC_OFF_TEST12 + cfg * 4 + 2])) R2(TILING12_1_1, 4)
+            R2(TILING12_1_2, 8)
+        }
+        case 13: {
+            for (int i = 0; i < 6; ++i)
+                if (mc_face_test(v, lut[MC_OFF_TEST13 + cfg * 7 + i])) sub |= 1 << i;
+            const int sc = lut[MC_OFF_SUBCONFIG13 + sub];
+            if (sc == 0) R2(TILING13_1, 4)
+            if (sc <= 6) R3(TILING13_2, sc - 1, 6)
+            if (sc <= 18) R3(TILING13_3, sc - 7, 10)
+            if (sc <= 22) R3(TILING13_4, sc - 19, 12)
+            if (sc <= 26) {
+                const int s5 = sc - 23;
+                if (mc_interior_test(lut, v, cas, cfg, s5, lut[MC_OFF_TEST13 + cfg * 7 + 6])) R3(TILING13_5_1, s5, 6)
+                R3(TILING13_5_2, s5, 10)
+            }
+            if (sc <= 38) R3(TILING13_3_, sc - 27, 10)
+            if (sc <= 44) R3(TILING13_2_, sc - 39, 6)
+            if (sc == 45) R2(TILING13_1_, 4)
+            break;
+        }
+        case 14: R2(TILING14, 4)
+        default: break;
+    }
+#undef R2
+#undef R3
+    ntri = 0;
+    return -1;
+}
+
+// bit e of the result is set iff local edge e (0..11) is first used by THIS cell in sweep order
+__device__ __forceinline__ unsigned mc_owned_mask(int x, int y, int z) {
+    const bool x0 = x == 0, y0 = y == 0, z0 = z == 0;
+    unsigned m = 0;
+    m |= (y0 && z0) ? 1u << 0 : 0u;   // x-edge (dy0,dz0)
+    m |= z0 ? 1u << 2 : 0u;           // x-edge (dy1,dz0)
+    m |= y0 ? 1u << 4 : 0u;           // x-edge (dy0,dz1)
+    m |= 1u << 6;                     // x-edge (dy1,dz1)
+    m |= (x0 && z0) ? 1u << 3 : 0u;   // y-edge (dx0,dz0)
+    m |= z0 ? 1u << 1 : 0u;           // y-edge (dx1,dz0)
+    m |= x0 ? 1u << 7 : 0u;           // y-edge (dx0,dz1)
+    m |= 1u << 5;                     // y-edge (dx1,dz1)
+    m |= (x0 && y0) ? 1u << 8 : 0u;   // z-edge (dx0,dy0)
+    m |= y0 ? 1u << 9 : 0u;           // z-edge (dx1,dy0)
+    m |= x0 ? 1u << 11 : 0u;          // z-edge (dx0,dy1)
+    m |= 1u << 10;                    // z-edge (dx1,dy1)
+    m |= 1u << 12;                    // centre vertex
+    return m;
+}
+
+// slot of local edge e of cell (x,y,z) in the global edge->vertex table [voxel][4] (0: x-edge, 1: y-edge, 2: z-edge, 3: centre)
+__device__ __forceinline__ int64_t mc_edge_slot(const McDims &d, int x, int y, int z, int e) {
+    int dx = 0, dy = 0, dz = 0, j;
+    if (e < 8) {
+        int ee = e & 3;
+        dz = e >> 2;
+        if (ee == 0) j = 0;
+        else if (ee == 1) { dx = 1; j = 1; }
+        else if (ee == 2) { dy = 1; j = 0; }
+        else j = 1;
+    } else if (e < 12) {
+        j = 2;
+        if (e == 9) dx = 1;
+        else if (e == 10) { dx = 1; dy = 1; }
+        else if (e == 11) dy = 1;
+    } else {
+        j = 3;
+    }
+    return ((((int64_t)(z + dz) * d.n1 + (y + dy)) * d.n2 + (x + dx)) << 2) + j;
+}
+
+__global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restrict__ vol, McDims d, double level,
+                                                          int32_t *__restrict__ cinfo, unsigned long long *__restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    mc_stage_lut(lut);
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= d.ncells) return;
+    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+    double v[8];
+    mc_load_cell(vol, d, x, y, z, level, v);
+    int index = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) index |= (v[i] > 0.0) ? (1 << i) : 0;
+    int info = -1;
+    unsigned long long cnt = 0;
+    if (index != 0 && index != 255) {
+        int ntri = 0;
+        const int row = mc_resolve(lut, v, index, ntri);
+        if (row >= 0 && ntri > 0) {
+            unsigned used = 0;
+            for (int k = 0; k < ntri * 3; ++k) used |= 1u << lut[row + k];
+            const int nnew = __popc(used & mc_owned_mask(x, y, z));
+            info = row | (ntri << 16);
+            cnt = ((unsigned long long)nnew << 32) | (unsigned)ntri;
+        }
+    }
+    cinfo[ci] = info;
+    counts[ci] = cnt;
+}
+
+// ---- exclusive scan of packed (nv<<32 | nt) counts, 1024 elements per block
+#define SCAN_ELEMS 1024
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *total) {
+    __shared__ unsigned long long wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const unsigned long long *__restrict__ in, int64_t n,
+                                                              unsigned long long *__restrict__ bsum) {
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    unsigned long long s = 0;
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) s += in[i0 + k];
+    unsigned long long tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void scan_top_kernel(unsigned long long *__restrict__ bsum, int64_t nb,
+                                                       unsigned long long *__restrict__ total_out) {
+    __shared__ unsigned long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        unsigned long long v = i < nb ? bsum[i] : 0, tot;
+        unsigned long long ex = block_excl_scan(v, &tot);
+        const unsigned long long carry = carry_s;
+        if (i < nb) bsum[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned long long *__restrict__ in, int64_t n,
+                                                         const unsigned long long *__restrict__ bsum,
+                                                         unsigned long long *__restrict__ out) {
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
+    unsigned long long v[4], s = 0;
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? in[i0 + k] : 0; s += v[k]; }
+    unsigned long long tot;
+    unsigned long long ex = block_excl_scan(s, &tot) + bsum[blockIdx.x];
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n) out[i0 + k] = ex;
+        ex += v[k];
+    }
+}
+
+// inverse-|value| weights of the two end corners of local edge e; i1/i2 are BIT-ORDER corner ids (x + 2y + 4z)
+__device__ __forceinline__ void mc_edge_weights(const int8_t *lut, const double *vv, int e, int &i1, int &i2, double &w1, double &w2,
+                                                const int8_t *&rel) {
+    rel = lut + MC_OFF_EDGEREL + e * 6;
+    i1 = rel[2] * 4 + rel[1] * 2 + rel[0];
+    i2 = rel[5] * 4 + rel[4] * 2 + rel[3];
+    w1 = __ddiv_rn(1.0, __dadd_rn(DBL_EPSILON, fabs(vv[i1])));
+    w2 = __ddiv_rn(1.0, __dadd_rn(DBL_EPSILON, fabs(vv[i2])));
+}
+
+// corner "gradients": table laid out in Lewiner corner order; scikit-image indexes it with the bit-order id for edge
+// vertices (upstream quirk, reproduced) and with the Lewiner id for the centre vertex.
+__device__ __forceinline__ double mc_vg(const double *v, int k, int comp) {
+    switch (k * 3 + comp) {
+        case 0: return __dsub_rn(v[0], v[1]); case 1: return __dsub_rn(v[0], v[3]); case 2: return __dsub_rn(v[0], v[4]);
+        case 3: return __dsub_rn(v[0], v[1]); case 4: return __dsub_rn(v[1], v[2]); case 5: return __dsub_rn(v[1], v[5]);
+        case 6: return __dsub_rn(v[3], v[2]); case 7: return __dsub_rn(v[1], v[2]); case 8: return __dsub_rn(v[2], v[6]);
+        case 9: return __dsub_rn(v[3], v[2]); case 10: return __dsub_rn(v[0], v[3]); case 11: return __dsub_rn(v[3], v[7]);
+        case 12: return __dsub_rn(v[4], v[5]); case 13: return __dsub_rn(v[4], v[7]); case 14: return __dsub_rn(v[0], v[4]);
+        case 15: return __dsub_rn(v[4], v[5]); case 16: return __dsub_rn(v[5], v[6]); case 17: return __dsub_rn(v[1], v[5]);
+        case 18: return __dsub_rn(v[7], v[6]); case 19: return __dsub_rn(v[5], v[6]); case 20: return __dsub_rn(v[2], v[6]);
+        case 21: return __dsub_rn(v[7], v[6]); case 22: return __dsub_rn(v[4], v[7]); default: return __dsub_rn(v[3], v[7]);
+    }
+}
+
+__device__ __forceinline__ void mc_bit_order(const double *v, double *vv) {
+    vv[0] = v[0]; vv[1] = v[1]; vv[2] = v[3]; vv[3] = v[2]; vv[4] = v[4]; vv[5] = v[5]; vv[6] = v[7]; vv[7] = v[6];
+}
+
+// owners: vertex ids, positions, edge table
+__global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restrict__ vol, McDims d, double level,
+                                                          const int32_t *__restrict__ cinfo,
+                                                          const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
+                                                          float *__restrict__ verts, int64_t cap_v) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    mc_stage_lut(lut);
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= d.ncells) return;
+    const int info = cinfo[ci];
+    if (info < 0) return;
+    const int row = info & 0xffff, ntri = info >> 16;
+    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+    const unsigned owned = mc_owned_mask(x, y, z);
+    unsigned seen = 0;
+    int64_t vid = (int64_t)(offs[ci] >> 32);
+    double v[8], vv[8];
+    bool loaded = false;
+    for (int k = 0; k < ntri * 3; ++k) {
+        const int e = lut[row + k];
+        if (seen & (1u << e)) continue;
+        seen |= 1u << e;
+        if (!(owned & (1u << e))) continue;
+        if (!loaded) { mc_load_cell(vol, d, x, y, z, level, v); mc_bit_order(v, vv); loaded = true; }
+        double px, py, pz;
+        if (e == 12) {
+            double fx = 0, fy = 0, fz = 0, ff = 0;
+            const int LC[8] = {0, 1, 3, 2, 4, 5, 7, 6};  // Lewiner corner -> bit-order offsets (x | y<<1 | z<<2)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double w = __ddiv_rn(1.0, __dadd_rn(DBL_EPSILON, fabs(v[c])));
+                fx = __dadd_rn(fx, __dmul_rn((double)(LC[c] & 1), w));
+                fy = __dadd_rn(fy, __dmul_rn((double)((LC[c] >> 1) & 1), w));
+                fz = __dadd_rn(fz, __dmul_rn((double)(LC[c] >> 2), w));
+                ff = __dadd_rn(ff, w);
+            }
+            px = __dadd_rn((double)x, __ddiv_rn(fx, ff));
+            py = __dadd_rn((double)y, __ddiv_rn(fy, ff));
+            pz = __dadd_rn((double)z, __ddiv_rn(fz, ff));
+        } else {
+            int i1, i2;
+            double w1, w2;
+            const int8_t *rel;
+            mc_edge_weights(lut, vv, e, i1, i2, w1, w2, rel);
+            const double fx = __dadd_rn(__dmul_rn((double)rel[0], w1), __dmul_rn((double)rel[3], w2));
+            const double fy = __dadd_rn(__dmul_rn((double)rel[1], w1), __dmul_rn((double)rel[4], w2));
+            const double fz = __dadd_rn(__dmul_rn((double)rel[2], w1), __dmul_rn((double)rel[5], w2));
+            const double ff = __dadd_rn(w1, w2);
+            px = __dadd_rn((double)x, __ddiv_rn(fx, ff));
+            py = __dadd_rn((double)y, __ddiv_rn(fy, ff));
+            pz = __dadd_rn((double)z, __ddiv_rn(fz, ff));
+        }
+        edge_vid[mc_edge_slot(d, x, y, z, e)] = (int32_t)vid;
+        if (vid < cap_v) {
+            verts[vid * 3 + 0] = (float)pz;  // array-axis order (axis0, axis1, axis2)
+            verts[vid * 3 + 1] = (float)py;
+            verts[vid * 3 + 2] = (float)px;
+        }
+        ++vid;
+    }
+}
+
+__global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *__restrict__ cinfo,
+                                                       const unsigned long long *__restrict__ offs,
+                                                       const int32_t *__restrict__ edge_vid, int32_t *__restrict__ faces, int64_t cap_f) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    mc_stage_lut(lut);
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= d.ncells) return;
+    const int info = cinfo[ci];
+    if (info < 0) return;
+    const int row = info & 0xffff, ntri = info >> 16;
+    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+    const int64_t t0 = (int64_t)(offs[ci] & 0xffffffffull);
+    for (int k = 0; k < ntri * 3; ++k) {
+        const int64_t f = t0 + k / 3;
+        if (f < cap_f) faces[f * 3 + k % 3] = edge_vid[mc_edge_slot(d, x, y, z, lut[row + k])];
+    }
+}
+
+// per-vertex gather of normals / values over the adjacent cells in sweep order.  One thread per (voxel, slot).
+__global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level,
+                                                       const int32_t *__restrict__ cinfo, const int32_t *__restrict__ edge_vid,
+                                                       float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    mc_stage_lut(lut);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.nvox * 4) return;
+    const int64_t vid = edge_vid[t];
+    if (vid < 0 || vid >= cap_v) return;
+    const int j = (int)(t & 3);
+    const int64_t vx = t >> 2;
+    const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
+    // local edge id seen from the adjacent cell at offset (-a,-b) in the two transverse axes, a = fast transverse axis
+    //   x-edge: transverse (y,z): e(a,b) = {0,2,4,6}[a + 2b] ; y-edge: transverse (x,z): {3,1,7,5} ; z-edge: (x,y): {8,9,11,10}
+    const int EL[3][4] = {{0, 2, 4, 6}, {3, 1, 7, 5}, {8, 9, 11, 10}};
+    float nx = 0.f, ny = 0.f, nz = 0.f, val = 0.f;
+    const int ncell = (j == 3) ? 1 : 4;
+    for (int q = 0; q < ncell; ++q) {
+        int cx = x, cy = y, cz = z, e = 12;
+        if (j < 3) {
+            const int a = (q & 1) ? 0 : 1, b = (q & 2) ? 0 : 1;  // sweep order: (1,1),(0,1),(1,0),(0,0)
+            if (j == 0) { cy = y - a; cz = z - b; }
+            else if (j == 1) { cx = x - a; cz = z - b; }
+            else { cx = x - a; cy = y - b; }
+            e = EL[j][a + 2 * b];
+        }
+        if (cx < 0 || cy < 0 || cz < 0 || cx >= d.c2 || cy >= d.c1 || cz >= d.c0) continue;
+        const int info = cinfo[((int64_t)cz * d.c1 + cy) * d.c2 + cx];
+        if (info < 0) continue;
+        const int row = info & 0xffff, ntri = info >> 16;
+        int uses = 0;
+        for (int k = 0; k < ntri * 3; ++k) uses += (lut[row + k] == e) ? 1 : 0;
+        if (uses == 0) continue;
+        double v[8], vv[8];
+        mc_load_cell(vol, d, cx, cy, cz, level, v);
+        mc_bit_order(v, vv);
+        double vmin = 0.0, vmax = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { vmax = v[c] > vmax ? v[c] : vmax; vmin = v[c] < vmin ? v[c] : vmin; }
+        const float span = (float)__dsub_rn(vmax, vmin);
+        val = span > val ? span : val;
+        if (e == 12) {
+            // pinned scikit-image quirk: centre gradient stored as (x <- z-sum, y <- y-sum, z <- 0)
+            double gy = 0, gz = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double w = __ddiv_rn(1.0, __dadd_rn(DBL_EPSILON, fabs(v[c])));
+                gy = __dadd_rn(gy, __dmul_rn(w, mc_vg(v, c, 1)));
+                gz = __dadd_rn(gz, __dmul_rn(w, mc_vg(v, c, 2)));
+            }
+            const float cgx = (float)gz, cgy = (float)gy;
+            for (int u = 0; u < uses; ++u) { nx = __fadd_rn(nx, cgx); ny = __fadd_rn(ny, cgy); nz = __fadd_rn(nz, 0.f); }
+        } else {
+            int i1, i2;
+            double w1, w2;
+            const int8_t *rel;
+            mc_edge_weights(lut, vv, e, i1, i2, w1, w2, rel);
+            const float s1 = (float)w1, s2 = (float)w2;
+            const float g1x = (float)__dmul_rn(mc_vg(v, i1, 0), (double)s1), g1y = (float)__dmul_rn(mc_vg(v, i1, 1), (double)s1),
+                        g1z = (float)__dmul_rn(mc_vg(v, i1, 2), (double)s1);
+            const float g2x = (float)__dmul_rn(mc_vg(v, i2, 0), (double)s2), g2y = (float)__dmul_rn(mc_vg(v, i2, 1), (double)s2),
+                        g2z = (float)__dmul_rn(mc_vg(v, i2, 2), (double)s2);
+            for (int u = 0; u < uses; ++u) {
+                nx = __fadd_rn(__fadd_rn(nx, g1x), g2x);
+                ny = __fadd_rn(__fadd_rn(ny, g1y), g2y);
+                nz = __fadd_rn(__fadd_rn(nz, g1z), g2z);
+            }
+        }
+    }
+    const double a = nz, b = ny, c = nx;  // array-axis order
+    const double len = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)), __dmul_rn(c, c)));
+    float o0 = nz, o1 = ny, o2 = nx;
+    if (len > 0.0) { o0 = (float)__ddiv_rn(a, len); o1 = (float)__ddiv_rn(b, len); o2 = (float)__ddiv_rn(c, len); }
+    normals[vid * 3 + 0] = o0;
+    normals[vid * 3 + 1] = o1;
+    normals[vid * 3 + 2] = o2;
+    values[vid] = val;
+}
+
+__global__ void mc_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts_dev) {
+    counts_dev[0] = (int64_t)(*total >> 32);
+    counts_dev[1] = (int64_t)(*total & 0xffffffffull);
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t gn_mc33_workspace_bytes(int n0, int n1, int n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+    const size_t ncells = (size_t)(n0 - 1) * (n1 - 1) * (n2 - 1), nvox = (size_t)n0 * n1 * n2;
+    const size_t nb = (ncells + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    return align256(ncells * 4) + 2 * align256(ncells * 8) + align256(nvox * 16) + align256((nb + 1) * 8) + 256;
+}
+
+extern "C" int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                       int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev,
+                       void *stream) {
+    GN_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "gn_mc33: input volume must be at least 2x2x2");
+    GN_REQUIRE(ws != nullptr && ws_bytes >= gn_mc33_workspace_bytes(n0, n1, n2), "gn_mc33: workspace too small");
+    GN_REQUIRE(cap_v >= 0 && cap_f >= 0, "gn_mc33: bad capacities");
+    McDims d;
+    d.n0 = n0; d.n1 = n1; d.n2 = n2; d.c0 = n0 - 1; d.c1 = n1 - 1; d.c2 = n2 - 1;
+    d.ncells = (int64_t)d.c0 * d.c1 * d.c2;
+    d.nvox = (int64_t)n0 * n1 * n2;
+    const int64_t nb = gn_cdiv(d.ncells, SCAN_ELEMS);
+    char *p = (char *)ws;
+    int32_t *cinfo = (int32_t *)p; p += align256(d.ncells * 4);
+    unsigned long long *counts = (unsigned long long *)p; p += align256(d.ncells * 8);
+    unsigned long long *offs = (unsigned long long *)p; p += align256(d.ncells * 8);
+    int32_t *edge_vid = (int32_t *)p; p += align256(d.nvox * 16);
+    unsigned long long *bsum = (unsigned long long *)p; p += align256((nb + 1) * 8);
+    unsigned long long *total = bsum + nb;
+    hipStream_t st = gn_stream(stream);
+    GN_HIP(hipMemsetAsync(edge_vid, 0xff, (size_t)d.nvox * 16, st), "gn_mc33(memset)");
+    const dim3 blk(256), gcell((unsigned)gn_cdiv(d.ncells, 256));
+    hipLaunchKernelGGL(mc_classify_kernel, gcell, blk, 0, st, vol, d, level, cinfo, counts);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), blk, 0, st, counts, d.ncells, bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), blk, 0, st, bsum, nb, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), blk, 0, st, counts, d.ncells, bsum, offs);
+    hipLaunchKernelGGL(mc_counts_kernel, dim3(1), dim3(1), 0, st, total, counts_dev);
+    hipLaunchKernelGGL(mc_vertices_kernel, gcell, blk, 0, st, vol, d, level, cinfo, offs, edge_vid, verts, cap_v);
+    hipLaunchKernelGGL(mc_faces_kernel, gcell, blk, 0, st, d, cinfo, offs, edge_vid, faces, cap_f);
+    hipLaunchKernelGGL(mc_attrs_kernel, dim3((unsigned)gn_cdiv(d.nvox * 4, 256)), blk, 0, st, vol, d, level, cinfo, edge_vid, normals,
+                       values, cap_v);
+    GN_LAUNCH_CHECK("gn_mc33");
+    return GN_OK;
+}
+
+// ================================================================================================ vertex helpers
+__global__ __launch_bounds__(256) void gather_nn_kernel(const float *__restrict__ vol, int n0, int n1, int n2,
+                                                        const float *__restrict__ verts_vox, int64_t nv, double spacing,
+                                                        float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    int id[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // numpy: (float32 vert * float64 spacing) / spacing -> astype(uint32)
+        const double scaled = __dmul_rn((double)verts_vox[i * 3 + a], spacing);
+        const double q = __ddiv_rn(scaled, spacing);
+        long long k = (long long)q;
+        const int lim = (a == 0 ? n0 : (a == 1 ? n1 : n2)) - 1;
+        k = k < 0 ? 0 : (k > lim ? lim : k);
+        id[a] = (int)k;
+    }
+    out[i] = vol[((int64_t)id[0] * n1 + id[1]) * n2 + id[2]];
+}
+
+extern "C" int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
+                            float *out, void *stream) {
+    GN_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && nv >= 0 && spacing > 0, "gn_gather_nn: bad sizes");
+    if (nv == 0) return GN_OK;
+    hipLaunchKernelGGL(gather_nn_kernel, dim3((unsigned)gn_cdiv(nv, 256)), dim3(256), 0, gn_stream(stream), vol, n0, n1, n2, verts_vox, nv,
+                       spacing, out);
+    GN_LAUNCH_CHECK("gn_gather_nn");
+    return GN_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_verts_kernel(const float *__restrict__ in, int64_t n3, double spacing,
+                                                          float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) out[i] = (float)__dmul_rn((double)in[i], spacing);
+}
+
+extern "C" int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *verts_out, void *stream) {
+    GN_REQUIRE(nv >= 0, "gn_scale_verts: bad sizes");
+    if (nv == 0) return GN_OK;
+    hipLaunchKernelGGL(scale_verts_kernel, dim3((unsigned)gn_cdiv(nv * 3, 256)), dim3(256), 0, gn_stream(stream), verts_vox, nv * 3,
+                       spacing, verts_out);
+    GN_LAUNCH_CHECK("gn_scale_verts");
+    return GN_OK;
+}

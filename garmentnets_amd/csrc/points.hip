@@ -1,0 +1,427 @@
+// points.hip -- PointNet++ point-set operators for gfx950 (wave64).
+//   gn_segment_ptr, gn_fps, gn_ball_query, gn_sa_gather, gn_segment_max, gn_global_max_pool,
+//   gn_knn_interpolate, gn_nocs_head
+// Reference call sites: /root/reference/components/pointnet2.py:22-76, networks/conv_implicit_wnf.py:220-231.
+#include <stdarg.h>
+#include <limits.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void gn_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *gn_last_error(void) { return g_err; }
+extern "C" int gn_version(void) { return 100; }
+extern "C" int gn_device_info(int *num_cu, int *lds_bytes_per_cu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    GN_HIP(hipGetDevice(&dev), "gn_device_info");
+    GN_HIP(hipGetDeviceProperties(&p, dev), "gn_device_info");
+    if (num_cu) *num_cu = p.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ segment ptr
+__global__ void segment_ptr_kernel(const int64_t *__restrict__ batch, int64_t n, int B, int32_t *__restrict__ ptr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    // ptr[b] = first i with batch[i] >= b ; element i opens segments (batch[i-1], batch[i]]
+    int64_t lo = (i == 0) ? -1 : batch[i - 1];
+    int64_t hi = (i == n) ? (int64_t)B : batch[i];
+    if (hi > B) hi = B;
+    for (int64_t b = lo + 1; b <= hi; ++b) ptr[b] = (int32_t)i;
+}
+
+extern "C" int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *ptr, void *stream) {
+    GN_REQUIRE(n >= 0 && B >= 0 && n < INT32_MAX, "gn_segment_ptr: bad sizes");
+    int64_t blocks = gn_cdiv(n + 1, 256);
+    hipLaunchKernelGGL(segment_ptr_kernel, dim3((unsigned)blocks), dim3(256), 0, gn_stream(stream), batch, n, B, ptr);
+    GN_LAUNCH_CHECK("gn_segment_ptr");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ FPS
+// One 1024-thread workgroup per example.  Thread t owns points t, t+1024, ... (PPT of them) and keeps their
+// coordinates and running min-distance in registers; a SoA copy of the positions lives in LDS so that every
+// thread can fetch the newly selected point by broadcast read.  Per step: fused (min-update, local arg-max),
+// 64-lane butterfly arg-max, one LDS exchange of 16 wave partials (double-buffered by step parity -> a single
+// barrier per step).  Key = (dist, lowest index wins).
+#define FPS_THREADS 1024
+#define FPS_WAVES (FPS_THREADS / 64)
+
+__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+template <int PPT, bool LDS_POS>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
+                                                         const int32_t *__restrict__ out_ptr, int32_t *__restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int s = ptr[b], n = ptr[b + 1] - s;
+    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
+    if (n <= 0 || m <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *pv = smem;                       // [2][FPS_WAVES] partial values
+    int *pi = (int *)(smem + 2 * FPS_WAVES);  // [2][FPS_WAVES] partial indices
+    float *lx = smem + 4 * FPS_WAVES;       // SoA positions (LDS_POS only)
+    float *ly = lx + n, *lz = ly + n;
+    const float *gp = pos + 3 * (size_t)s;
+
+    float px[PPT], py[PPT], pz[PPT], dd[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int i = tid + j * FPS_THREADS;
+        if (i < n) {
+            px[j] = gp[3 * i]; py[j] = gp[3 * i + 1]; pz[j] = gp[3 * i + 2];
+            if (LDS_POS) { lx[i] = px[j]; ly[i] = py[j]; lz[i] = pz[j]; }
+        } else {
+            px[j] = py[j] = pz[j] = 0.f;
+        }
+        dd[j] = 3.0e38f;
+    }
+    if (LDS_POS) __syncthreads();
+    int last = 0;
+    if (tid == 0) out_idx[o0] = s;
+    for (int k = 1; k < m; ++k) {
+        float qx, qy, qz;
+        if (LDS_POS) { qx = lx[last]; qy = ly[last]; qz = lz[last]; }
+        else { qx = gp[3 * last]; qy = gp[3 * last + 1]; qz = gp[3 * last + 2]; }
+        float bv = -1.f;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            int i = tid + j * FPS_THREADS;
+            if (i < n) {
+                float d = gn_sqdist3(px[j], py[j], pz[j], qx, qy, qz);
+                d = fminf(dd[j], d);
+                dd[j] = d;
+                if (d > bv) { bv = d; bi = i; }  // ascending i: ties keep the lowest index
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(bv, off);
+            int oi = __shfl_xor(bi, off);
+            argmax_merge(bv, bi, ov, oi);
+        }
+        const int par = (k & 1) * FPS_WAVES;
+        if (lane == 0) { pv[par + wave] = bv; pi[par + wave] = bi; }
+        __syncthreads();
+        float fv = pv[par];
+        int fi = pi[par];
+#pragma unroll
+        for (int w = 1; w < FPS_WAVES; ++w) argmax_merge(fv, fi, pv[par + w], pi[par + w]);
+        last = fi;
+        if (tid == 0) out_idx[o0 + k] = s + last;
+    }
+}
+
+extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, int B, int max_points_per_example,
+                      int32_t *out_idx, void *stream) {
+    GN_REQUIRE(B >= 0 && max_points_per_example >= 0, "gn_fps: bad sizes");
+    if (B == 0 || max_points_per_example == 0) return GN_OK;
+    const int n = max_points_per_example;
+    GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
+    const bool lds_pos = n <= 8192;
+    size_t sh = sizeof(float) * 4 * FPS_WAVES + (lds_pos ? sizeof(float) * 3 * (size_t)n : 0);
+    int ppt = (int)gn_cdiv(n, FPS_THREADS);
+#define FPS_LAUNCH(P, L)                                                                                        \
+    do {                                                                                                        \
+        GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
+        hipLaunchKernelGGL((fps_kernel<P, L>), dim3(B), dim3(FPS_THREADS), sh, gn_stream(stream), pos, ptr, out_ptr, out_idx); \
+    } while (0)
+    if (ppt <= 1) FPS_LAUNCH(1, true);
+    else if (ppt <= 2) FPS_LAUNCH(2, true);
+    else if (ppt <= 4) FPS_LAUNCH(4, true);
+    else if (ppt <= 6) FPS_LAUNCH(6, true);
+    else if (ppt <= 8) FPS_LAUNCH(8, true);
+    else FPS_LAUNCH(16, false);
+#undef FPS_LAUNCH
+    GN_LAUNCH_CHECK("gn_fps");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ball query
+// One wavefront per centre; the example's points are scanned 64 at a time in ascending index, the ballot of the
+// in-range predicate and a popcount prefix give each hit its ordered output slot; stop at K.
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
+                                                         const int32_t *__restrict__ centre_idx,
+                                                         const int32_t *__restrict__ centre_ptr, int B, int M, float r2, int K,
+                                                         int32_t *__restrict__ nbr, int32_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= M) return;
+    // example of this centre: binary search in centre_ptr
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (centre_ptr[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const int s = ptr[b], e = ptr[b + 1];
+    const int ci = centre_idx[c];
+    const float cx = pos[3 * (size_t)ci], cy = pos[3 * (size_t)ci + 1], cz = pos[3 * (size_t)ci + 2];
+    int32_t *row = nbr + (size_t)c * K;
+    int count = 0;
+    for (int base = s; base < e && count < K; base += 64) {
+        int j = base + lane;
+        bool in = false;
+        if (j < e) {
+            float d = gn_sqdist3(pos[3 * (size_t)j], pos[3 * (size_t)j + 1], pos[3 * (size_t)j + 2], cx, cy, cz);
+            in = d < r2;
+        }
+        unsigned long long mask = __ballot(in);
+        int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (in && count + before < K) row[count + before] = j;
+        count += __popcll(mask);
+    }
+    if (count > K) count = K;
+    for (int t = count + lane; t < K; t += 64) row[t] = -1;
+    if (lane == 0) cnt[c] = count;
+}
+
+extern "C" int gn_ball_query(const float *pos, const int32_t *ptr, const int32_t *centre_idx, const int32_t *centre_ptr,
+                             int B, int M, float r2, int K, int32_t *nbr, int32_t *cnt, void *stream) {
+    GN_REQUIRE(B >= 0 && M >= 0 && K > 0, "gn_ball_query: bad sizes");
+    if (M == 0) return GN_OK;
+    hipLaunchKernelGGL(ball_query_kernel, dim3((unsigned)gn_cdiv(M, 4)), dim3(256), 0, gn_stream(stream), pos, ptr, centre_idx,
+                       centre_ptr, B, M, r2, K, nbr, cnt);
+    GN_LAUNCH_CHECK("gn_ball_query");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SA gather
+// one wave per (centre, slot) row
+__global__ __launch_bounds__(256) void sa_gather_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ pos,
+                                                        const int32_t *__restrict__ centre_idx, const int32_t *__restrict__ nbr,
+                                                        int M, int K, int self_loops, float *__restrict__ out, int ldo,
+                                                        int32_t *__restrict__ slot_src) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int S = K + (self_loops ? 1 : 0);
+    if (row >= (int64_t)M * S) return;
+    const int c = (int)(row / S), sl = (int)(row % S);
+    int j;
+    if (sl < K) {
+        j = nbr[(size_t)c * K + sl];
+        if (self_loops && j == c) j = -1;  // remove_self_loops on numeric equality source == target
+    } else {
+        j = c;  // add_self_loops(num_nodes = M): source = point c of the full cloud
+    }
+    float *o = out + row * (int64_t)ldo;
+    if (lane == 0) slot_src[row] = j;
+    if (j < 0) {
+        for (int t = lane; t < C + 3; t += 64) o[t] = 0.f;
+        return;
+    }
+    const float *xr = x ? x + (size_t)j * ldx : nullptr;
+    for (int t = lane; t < C; t += 64) o[t] = xr[t];
+    if (lane < 3) {
+        int ci = centre_idx[c];
+        o[C + lane] = __fsub_rn(pos[3 * (size_t)j + lane], pos[3 * (size_t)ci + lane]);
+    }
+}
+
+extern "C" int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                            int M, int K, int self_loops, float *out, int ldo, int32_t *slot_src, void *stream) {
+    GN_REQUIRE(M >= 0 && K > 0 && C >= 0 && ldo >= C + 3, "gn_sa_gather: bad sizes");
+    GN_REQUIRE(C == 0 || x != nullptr, "gn_sa_gather: x is NULL with C>0");
+    if (M == 0) return GN_OK;
+    int64_t rows = (int64_t)M * (K + (self_loops ? 1 : 0));
+    hipLaunchKernelGGL(sa_gather_kernel, dim3((unsigned)gn_cdiv(rows, 4)), dim3(256), 0, gn_stream(stream), x, ldx, C, pos,
+                       centre_idx, nbr, M, K, self_loops, out, ldo, slot_src);
+    GN_LAUNCH_CHECK("gn_sa_gather");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ segment max
+__global__ __launch_bounds__(256) void segment_max_kernel(const float *__restrict__ in, int ldi, const int32_t *__restrict__ slot_src,
+                                                          int M, int S, int C, float *__restrict__ out, int ldo) {
+    const int c = blockIdx.x;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float v = 0.f;
+        bool any = false;
+        for (int s = 0; s < S; ++s) {
+            int64_t row = (int64_t)c * S + s;
+            if (slot_src[row] < 0) continue;
+            float t = in[row * ldi + ch];
+            v = any ? fmaxf(v, t) : t;
+            any = true;
+        }
+        out[(int64_t)c * ldo + ch] = v;  // no valid slot -> 0 (scatter-max of nothing)
+    }
+}
+
+extern "C" int gn_segment_max(const float *in, int ldi, const int32_t *slot_src, int M, int S, int C, float *out, int ldo,
+                              void *stream) {
+    GN_REQUIRE(M >= 0 && S > 0 && C > 0, "gn_segment_max: bad sizes");
+    if (M == 0) return GN_OK;
+    int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(segment_max_kernel, dim3(M), dim3(threads), 0, gn_stream(stream), in, ldi, slot_src, M, S, C, out, ldo);
+    GN_LAUNCH_CHECK("gn_segment_max");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ global max pool
+// grid (B, channel tiles of 64); each block: 256 threads = 4 row-groups x 64 channels, LDS combine.
+__global__ __launch_bounds__(256) void global_max_kernel(const float *__restrict__ in, int ldi, const int32_t *__restrict__ ptr,
+                                                         int C, float *__restrict__ out, int ldo) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int s = ptr[b], e = ptr[b + 1];
+    float v = -3.4e38f;
+    if (ch < C)
+        for (int r = s + g; r < e; r += 4) v = fmaxf(v, in[(int64_t)r * ldi + ch]);
+    part[g][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (g == 0 && ch < C) {
+        v = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+        out[(int64_t)b * ldo + ch] = (e > s) ? v : 0.f;
+    }
+}
+
+extern "C" int gn_global_max_pool(const float *in, int ldi, const int32_t *ptr, int B, int C, float *out, int ldo, void *stream) {
+    GN_REQUIRE(B >= 0 && C > 0, "gn_global_max_pool: bad sizes");
+    if (B == 0) return GN_OK;
+    hipLaunchKernelGGL(global_max_kernel, dim3(B, (unsigned)gn_cdiv(C, 64)), dim3(256), 0, gn_stream(stream), in, ldi, ptr, C, out, ldo);
+    GN_LAUNCH_CHECK("gn_global_max_pool");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ kNN interpolate
+// One wavefront per query.  Each lane keeps the k best (d2, idx) of the sources it scanned (ascending, ties ->
+// lower index), then k rounds of wave arg-min pop the global k best in ascending order; the weighted feature sum
+// is then computed with channels spread over lanes, accumulating in that order.
+#define KNN_MAXK 8
+template <int KK>
+__global__ __launch_bounds__(256) void knn_interp_kernel(const float *__restrict__ xs, int ldx, const float *__restrict__ ps,
+                                                         const int32_t *__restrict__ ptr_s, const float *__restrict__ pq,
+                                                         const int32_t *__restrict__ ptr_q, int B, int Nq, int C,
+                                                         float *__restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= Nq) return;
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ptr_q[mid] <= q) lo = mid; else hi = mid;
+    }
+    const int s = ptr_s[lo], e = ptr_s[lo + 1];
+    const float qx = pq[3 * (size_t)q], qy = pq[3 * (size_t)q + 1], qz = pq[3 * (size_t)q + 2];
+    float bd[KK];
+    int bi[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) { bd[t] = 3.4e38f; bi[t] = INT_MAX; }
+    for (int j = s + lane; j < e; j += 64) {
+        float d = gn_sqdist3(ps[3 * (size_t)j], ps[3 * (size_t)j + 1], ps[3 * (size_t)j + 2], qx, qy, qz);
+        // insert (d, j) into the ascending list; j ascends within a lane so strict '<' keeps lower indices first
+        if (d < bd[KK - 1]) {
+            bd[KK - 1] = d; bi[KK - 1] = j;
+#pragma unroll
+            for (int t = KK - 1; t > 0; --t) {
+                if (bd[t] < bd[t - 1]) {
+                    float td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
+                    int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
+                }
+            }
+        }
+    }
+    float wd[KK];
+    int wi[KK];
+    int nsel = 0;
+#pragma unroll
+    for (int r = 0; r < KK; ++r) {
+        float v = bd[0];
+        int i = bi[0];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(v, off);
+            int oi = __shfl_xor(i, off);
+            if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        wd[r] = v; wi[r] = i;
+        if (i != INT_MAX) nsel = r + 1;
+        if (bi[0] == i && i != INT_MAX) {  // the owner pops its head
+#pragma unroll
+            for (int t = 0; t < KK - 1; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
+            bd[KK - 1] = 3.4e38f; bi[KK - 1] = INT_MAX;
+        }
+    }
+    float w[KK];
+    float wsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < KK; ++r) {
+        if (r < nsel) {
+            float d = wd[r] < 1e-16f ? 1e-16f : wd[r];
+            w[r] = __fdiv_rn(1.0f, d);
+            wsum = __fadd_rn(wsum, w[r]);
+        } else w[r] = 0.f;
+    }
+    for (int ch = lane; ch < C; ch += 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < KK; ++r)
+            if (r < nsel) acc = __fadd_rn(acc, __fmul_rn(xs[(size_t)wi[r] * ldx + ch], w[r]));
+        out[(size_t)q * ldo + ch] = __fdiv_rn(acc, wsum);
+    }
+}
+
+extern "C" int gn_knn_interpolate(const float *xs, int ldx, const float *ps, const int32_t *ptr_s, const float *pq,
+                                  const int32_t *ptr_q, int B, int Nq, int C, int k, float *out, int ldo, void *stream) {
+    GN_REQUIRE(k >= 1 && k <= KNN_MAXK, "gn_knn_interpolate: k must be in [1,%d]", KNN_MAXK);
+    GN_REQUIRE(B >= 0 && Nq >= 0 && C > 0, "gn_knn_interpolate: bad sizes");
+    if (Nq == 0) return GN_OK;
+    dim3 grid((unsigned)gn_cdiv(Nq, 4)), block(256);
+#define KNN_LAUNCH(KK) hipLaunchKernelGGL((knn_interp_kernel<KK>), grid, block, 0, gn_stream(stream), xs, ldx, ps, ptr_s, pq, ptr_q, B, Nq, C, out, ldo)
+    switch (k) {
+        case 1: KNN_LAUNCH(1); break;
+        case 2: KNN_LAUNCH(2); break;
+        case 3: KNN_LAUNCH(3); break;
+        case 4: KNN_LAUNCH(4); break;
+        default: KNN_LAUNCH(8); break;
+    }
+#undef KNN_LAUNCH
+    GN_LAUNCH_CHECK("gn_knn_interpolate");
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ NOCS head
+// one thread per (point, axis): arg-max over the bins (first maximum), soft-max value at it, bin -> coordinate.
+__global__ __launch_bounds__(256) void nocs_head_kernel(const float *__restrict__ logits, int ldl, int64_t N, int bins,
+                                                        int64_t *__restrict__ bin_idx, float *__restrict__ conf,
+                                                        float *__restrict__ nocs) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * 3) return;
+    int64_t p = t / 3;
+    int a = (int)(t % 3);
+    const float *row = logits + p * ldl;
+    float mx = row[a];
+    int arg = 0;
+    for (int k = 1; k < bins; ++k) {
+        float v = row[k * 3 + a];
+        if (v > mx) { mx = v; arg = k; }
+    }
+    float sum = 0.f;
+    for (int k = 0; k < bins; ++k) sum = __fadd_rn(sum, expf(__fsub_rn(row[k * 3 + a], mx)));
+    bin_idx[t] = arg;
+    conf[t] = __fdiv_rn(1.0f, sum);  // exp(mx-mx)/sum
+    const float scale = __fdiv_rn(1.0f, __fsub_rn((float)bins, 1.0f));  // (uc-lc)/(bins-1) in fp32, gridding.py:252
+    nocs[t] = __fadd_rn(__fmul_rn((float)arg, scale), 0.0f);
+}
+
+extern "C" int gn_nocs_head(const float *logits, int ldl, int64_t N, int bins, int64_t *bin_idx, float *confidence,
+                            float *pred_nocs, void *stream) {
+    GN_REQUIRE(N >= 0 && bins > 0 && ldl >= bins * 3, "gn_nocs_head: bad sizes");
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(nocs_head_kernel, dim3((unsigned)gn_cdiv(N * 3, 256)), dim3(256), 0, gn_stream(stream), logits, ldl, N, bins,
+                       bin_idx, confidence, pred_nocs);
+    GN_LAUNCH_CHECK("gn_nocs_head");
+    return GN_OK;
+}

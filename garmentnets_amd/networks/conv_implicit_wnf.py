@@ -1,0 +1,176 @@
+"""ConvImplicitWNFPipeline (inference) -- API twin of /root/reference/networks/conv_implicit_wnf.py:23-338.
+
+Keeps the reference's class names, constructor kwargs, sub-module names (= checkpoint schema: ``pointnet2_nocs``,
+``volume_agg.local_nn``, ``unet_3d.abstract_3d_unet``, ``volume_decoder.mlp`` ...), stage methods
+(``pointnet2_forward``, ``unet3d_forward``, ``volume_decoder_forward``, ``surface_decoder_forward``,
+``mc_surface_decoder_forward``, ``forward``) and result-dict keys, so that predict.py is a drop-in.  Training code
+(:340-452) is out of scope.  Feature volumes are stored channel-last; the (B,C,D,H,W) tensors handed out are views.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..batch import Batch
+from ..components.mlp import MLP
+from ..components.unet3d import Abstract3DUNet, DoubleConv, to_channel_last
+from .pointnet2_nocs import PointNet2NOCS
+
+
+class VolumeFeatureAggregator(nn.Module):
+    """per-point MLP -> scatter (max | mean) into a (B,C,G,G,G) volume -- conv_implicit_wnf.py:23-100."""
+
+    def __init__(self, nn_channels=[1024, 1024, 128], batch_norm=True, lower_corner=(0, 0, 0), upper_corner=(1, 1, 1),
+                 grid_shape=(32, 32, 32), reduce_method="mean", include_point_feature=True, include_confidence_feature=False):
+        super().__init__()
+        self.local_nn = MLP(nn_channels, batch_norm=batch_norm)
+        self.lower_corner = tuple(lower_corner)
+        self.upper_corner = tuple(upper_corner)
+        self.grid_shape = tuple(grid_shape)
+        self.reduce_method = reduce_method
+        self.include_point_feature = include_point_feature
+        self.include_confidence_feature = include_confidence_feature
+
+    def forward(self, nocs_data):
+        B = nocs_data.num_graphs
+        conf = nocs_data.pred_confidence
+        feats, flat = ops.grid_features(nocs_data.x, nocs_data.pos.contiguous(), nocs_data.sim_points.float().contiguous(),
+                                        conf.contiguous(), nocs_data.batch, self.lower_corner, self.upper_corner, self.grid_shape,
+                                        self.include_point_feature, self.include_confidence_feature)
+        if self.local_nn is not None:
+            feats = self.local_nn(feats)
+        vol = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method)      # [B][G][G][G][C]
+        return vol.permute(0, 4, 1, 2, 3)
+
+
+class UNet3D(nn.Module):
+    def __init__(self, in_channels, out_channels, f_maps=64, layer_order="gcr", num_groups=8, num_levels=4):
+        super().__init__()
+        self.abstract_3d_unet = Abstract3DUNet(in_channels=in_channels, out_channels=out_channels, final_sigmoid=False,
+                                               basic_module=DoubleConv, f_maps=f_maps, layer_order=layer_order,
+                                               num_groups=num_groups, num_levels=num_levels, is_segmentation=False)
+
+    def forward(self, data):
+        return self.abstract_3d_unet(data)
+
+
+class ImplicitWNFDecoder(nn.Module):
+    """trilinear feature sampling (border, align_corners) -> MLP -- conv_implicit_wnf.py:120-149."""
+
+    ROWS_PER_CHUNK = 1 << 19
+
+    def __init__(self, nn_channels=(128, 512, 512, 1), batch_norm=True):
+        super().__init__()
+        self.mlp = MLP(list(nn_channels), batch_norm=batch_norm)
+        self.out_channels = nn_channels[-1]
+
+    def _decode_rows(self, vol_b, out, query=None, Q=0):
+        M = out.shape[0]
+        for m0 in range(0, M, self.ROWS_PER_CHUNK):
+            m = min(self.ROWS_PER_CHUNK, M - m0)
+            if query is not None:
+                s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m])
+            else:
+                s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m)
+            out[m0:m0 + m] = self.mlp(s)
+
+    def forward(self, features_grid, query_points):
+        """features_grid (B,C,D,H,W), query_points (B,M,3) in [0,1] -> (B,M,out)"""
+        vol = to_channel_last(features_grid)
+        B, M = query_points.shape[:2]
+        q = query_points.float().contiguous()
+        out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=vol.device)
+        for b in range(B):
+            self._decode_rows(vol[b], out[b], query=q[b])
+        return out
+
+    def decode_lattice(self, features_grid, Q):
+        """All (Q,Q,Q) lattice queries of predict.py:145-157 without materialising them -> (B,Q,Q,Q[,out])"""
+        vol = to_channel_last(features_grid)
+        B = vol.shape[0]
+        out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
+        for b in range(B):
+            self._decode_rows(vol[b], out[b], Q=Q)
+        return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
+
+
+class ConvImplicitWNFPipeline(nn.Module):
+    def __init__(self, pointnet2_params, volume_agg_params, unet3d_params, volume_decoder_params, surface_decoder_params,
+                 mc_surface_decoder_params=None, learning_rate=1e-4, loss_type="l2", volume_loss_weight=1.0,
+                 surface_loss_weight=1.0, mc_surface_loss_weight=0, volume_classification=False, volume_task_space=False,
+                 vis_per_items=0, max_vis_per_epoch_train=0, max_vis_per_epoch_val=0, batch_size=None):
+        super().__init__()
+        self.hparams = dict(pointnet2_params=dict(pointnet2_params), volume_agg_params=dict(volume_agg_params),
+                            unet3d_params=dict(unet3d_params), volume_decoder_params=dict(volume_decoder_params),
+                            surface_decoder_params=dict(surface_decoder_params),
+                            mc_surface_decoder_params=None if mc_surface_decoder_params is None else dict(mc_surface_decoder_params),
+                            mc_surface_loss_weight=mc_surface_loss_weight, volume_task_space=volume_task_space)
+        self.pointnet2_nocs = PointNet2NOCS(**pointnet2_params)
+        self.volume_agg = VolumeFeatureAggregator(**volume_agg_params)
+        self.unet_3d = UNet3D(**unet3d_params)
+        self.volume_decoder = ImplicitWNFDecoder(**volume_decoder_params)
+        self.surface_decoder = ImplicitWNFDecoder(**surface_decoder_params)
+        self.mc_surface_decoder = None
+        if mc_surface_loss_weight > 0:
+            self.mc_surface_decoder = ImplicitWNFDecoder(**mc_surface_decoder_params)
+        self.volume_task_space = volume_task_space
+        self.batch_size = batch_size
+
+    # -- checkpoint ------------------------------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", **overrides):
+        """Reads a Lightning-style checkpoint {'state_dict', 'hyper_parameters'} (predict.py:101) without Lightning."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+        hp = dict(ckpt["hyper_parameters"])
+        hp.update(overrides)
+        model = cls(**hp)
+        model.load_state_dict(ckpt["state_dict"])
+        return model
+
+    def save_checkpoint(self, path):
+        torch.save({"state_dict": self.state_dict(), "hyper_parameters": self.hparams}, path)
+
+    @property
+    def device(self):
+        return self.pointnet2_nocs.device
+
+    # -- stages ----------------------------------------------------------------------------------------------
+    def pointnet2_forward(self, data):
+        result = self.pointnet2_nocs(data)
+        bins = self.pointnet2_nocs.nocs_bins
+        _, confidence, pred_nocs = ops.nocs_head(result["per_point_logits"], bins)
+        result["nocs_data"] = Batch(sizes=self.pointnet2_nocs.last_sizes, x=result["per_point_features"], pos=pred_nocs, batch=result["per_point_batch_idx"],
+                                    sim_points=data.pos, pred_confidence=confidence)
+        return result
+
+    def unet3d_forward(self, pointnet2_result):
+        in_feature_volume = self.volume_agg(pointnet2_result["nocs_data"])
+        return {"out_feature_volume": self.unet_3d(in_feature_volume)}
+
+    def volume_decoder_forward(self, unet3d_result, query_points):
+        out = self.volume_decoder(unet3d_result["out_feature_volume"], query_points)
+        return {"out_features": out, "pred_volume_value": out.view(*out.shape[:-1])}
+
+    def surface_decoder_forward(self, unet3d_result, query_points):
+        return {"out_features": self.surface_decoder(unet3d_result["out_feature_volume"], query_points)}
+
+    def mc_surface_decoder_forward(self, unet3d_result, query_points):
+        return {"out_features": self.mc_surface_decoder(unet3d_result["out_feature_volume"], query_points)}
+
+    def volume_lattice_forward(self, unet3d_result, volume_size):
+        """Whole (Q,Q,Q) WNF volume per garment in one pass (replaces the 64^3 chunk loop of predict.py:145-157)."""
+        return {"pred_volume": self.volume_decoder.decode_lattice(unet3d_result["out_feature_volume"], volume_size)}
+
+    def forward(self, data):
+        if self.volume_task_space:
+            raise NotImplementedError("volume_task_space=True is a training-time variant (conv_implicit_wnf.py:279-311)")
+        p2 = self.pointnet2_forward(data)
+        u3 = self.unet3d_forward(p2)
+        result = {
+            "pointnet2_result": p2,
+            "unet3d_result": u3,
+            "volume_decoder_result": self.volume_decoder_forward(u3, data.volume_query_points),
+            "surface_decoder_result": self.surface_decoder_forward(u3, data.surf_query_points),
+        }
+        if self.mc_surface_decoder is not None:
+            result["mc_surface_decoder_result"] = self.mc_surface_decoder_forward(u3, data.mc_surf_query_points)
+        return result

@@ -1,0 +1,270 @@
+"""Thin torch-tensor wrappers over the C ABI (include/garmentnets_hip.h).
+
+torch is used for device memory and streams only; every function below launches hand-written HIP kernels on the
+current torch stream.  Tensors must live on a ROCm device -- there is no CPU path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_i32 = torch.int32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.GarmentNetsHipError("garmentnets_amd ops need tensors on the GPU (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def rows_view(t):
+    """(rows, ld) of a 2-D tensor whose rows are contiguous (stride(1)==1); ld = stride(0)."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), "need row-major rows"
+    return t.shape[0], (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def new_rows(n, c, device):
+    """[n][c] fp32 buffer whose leading dimension is padded to a multiple of 4 (16-byte rows for the GEMM loader)."""
+    buf = torch.empty((n, pad4(c)), dtype=torch.float32, device=device)
+    return buf[:, :c]
+
+
+# ------------------------------------------------------------------------------------------------ points
+def fps_count(n, ratio):
+    """torch_cluster: ceil(n * ratio) evaluated in float32."""
+    return int(math.ceil(float(np.float32(n) * np.float32(ratio))))
+
+
+def segment_ptr(batch, B):
+    _chk(batch, torch.int64, "batch")
+    ptr = torch.empty(B + 1, dtype=_i32, device=batch.device)
+    _lib.call("gn_segment_ptr", _p(batch), batch.numel(), B, _p(ptr), _stream())
+    return ptr
+
+
+def fps(pos, ptr, out_ptr, max_points, m_total):
+    _chk(pos, torch.float32, "pos")
+    idx = torch.empty(m_total, dtype=_i32, device=pos.device)
+    _lib.call("gn_fps", _p(pos), _p(ptr), _p(out_ptr), ptr.numel() - 1, int(max_points), _p(idx), _stream())
+    return idx
+
+
+def ball_query(pos, ptr, centre_idx, centre_ptr, r, K=64):
+    M = centre_idx.numel()
+    nbr = torch.empty((M, K), dtype=_i32, device=pos.device)
+    cnt = torch.empty(M, dtype=_i32, device=pos.device)
+    r2 = float(np.float32(float(r) * float(r)))
+    _lib.call("gn_ball_query", _p(pos), _p(ptr), _p(centre_idx), _p(centre_ptr), ptr.numel() - 1, M, r2, K, _p(nbr), _p(cnt), _stream())
+    return nbr, cnt
+
+
+def sa_gather(x, pos, centre_idx, nbr, self_loops=True):
+    M, K = nbr.shape
+    C = 0 if x is None else x.shape[1]
+    S = K + (1 if self_loops else 0)
+    out = new_rows(M * S, C + 3, pos.device)
+    slot_src = torch.empty(M * S, dtype=_i32, device=pos.device)
+    ldx = 0 if x is None else rows_view(x)[1]
+    _lib.call("gn_sa_gather", _p(x), ldx, C, _p(pos), _p(centre_idx), _p(nbr), M, K, 1 if self_loops else 0, _p(out),
+              out.stride(0), _p(slot_src), _stream())
+    return out, slot_src, S
+
+
+def segment_max(h, slot_src, M, S):
+    C = h.shape[1]
+    out = new_rows(M, C, h.device)
+    _lib.call("gn_segment_max", _p(h), rows_view(h)[1], _p(slot_src), M, S, C, _p(out), out.stride(0), _stream())
+    return out
+
+
+def global_max_pool(h, ptr, B):
+    C = h.shape[1]
+    out = new_rows(B, C, h.device)
+    _lib.call("gn_global_max_pool", _p(h), rows_view(h)[1], _p(ptr), B, C, _p(out), out.stride(0), _stream())
+    return out
+
+
+def knn_interpolate(xs, ps, ptr_s, pq, ptr_q, k, out=None):
+    Nq, C = pq.shape[0], xs.shape[1]
+    if out is None:
+        out = new_rows(Nq, C, xs.device)
+    _lib.call("gn_knn_interpolate", _p(xs), rows_view(xs)[1], _p(ps), _p(ptr_s), _p(pq), _p(ptr_q), ptr_s.numel() - 1, Nq, C,
+              int(k), _p(out), rows_view(out)[1], _stream())
+    return out
+
+
+def linear(x, w, bias=None, bn_scale=None, bn_shift=None, relu=False, out=None, K=None):
+    """x [M][K] rows, w [N][ldw] (packed, possibly K-padded) -> [M][N]."""
+    M = x.shape[0]
+    K = x.shape[1] if K is None else K
+    N = w.shape[0]
+    if out is None:
+        out = new_rows(M, N, x.device)
+    _lib.call("gn_linear", _p(x), rows_view(x)[1], _p(w), rows_view(w)[1], _p(bias), _p(bn_scale), _p(bn_shift), 1 if relu else 0,
+              M, N, K, _p(out), rows_view(out)[1], _stream())
+    return out
+
+
+def nocs_head(logits, bins):
+    N = logits.shape[0]
+    dev = logits.device
+    idx = torch.empty((N, 3), dtype=torch.int64, device=dev)
+    conf = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    nocs = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    _lib.call("gn_nocs_head", _p(logits), rows_view(logits)[1], N, bins, _p(idx), _p(conf), _p(nocs), _stream())
+    return idx, conf, nocs
+
+
+# ------------------------------------------------------------------------------------------------ gridding
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(a) for a in v])
+
+
+def _i3(v):
+    return (ctypes.c_int * 3)(*[int(a) for a in v])
+
+
+def grid_features(feat, nocs, sim_pos, conf, batch, lower, upper, grid_shape, include_point=True, include_conf=True):
+    N, Cf = feat.shape
+    C = Cf + (6 if include_point else 0) + (3 if include_conf else 0)
+    out = new_rows(N, C, feat.device)
+    flat = torch.empty(N, dtype=_i32, device=feat.device)
+    _lib.call("gn_grid_features", _p(feat), rows_view(feat)[1], Cf, _p(_chk(nocs, torch.float32, "nocs")),
+              _p(_chk(sim_pos, torch.float32, "sim_pos")), _p(_chk(conf, torch.float32, "conf")), _p(_chk(batch, torch.int64, "batch")),
+              N, _f3(lower), _f3(upper), _i3(grid_shape), 1 if include_point else 0, 1 if include_conf else 0, _p(out),
+              out.stride(0), _p(flat), _stream())
+    return out, flat
+
+
+def grid_scatter(src, flat_idx, B, grid_shape, reduce):
+    """-> channel-last volume [B][G0][G1][G2][C]"""
+    N, C = src.shape
+    cells = B * int(np.prod(grid_shape))
+    vol = torch.empty((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=src.device)
+    cnt = torch.empty(cells, dtype=_i32, device=src.device)
+    code = {"max": 0, "mean": 1}[reduce]
+    _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _stream())
+    return vol
+
+
+# ------------------------------------------------------------------------------------------------ UNet
+def channel_stats(x):
+    """x channel-last [B][D][H][W][C] -> (sum, sumsq) fp64 [B][C]"""
+    B, C = x.shape[0], x.shape[-1]
+    V = x.numel() // (B * C)
+    s = torch.empty((B, C), dtype=torch.float64, device=x.device)
+    q = torch.empty((B, C), dtype=torch.float64, device=x.device)
+    _lib.call("gn_channel_stats", _p(x), B, V, C, _p(s), _p(q), _stream())
+    return s, q, V
+
+
+def groupnorm_affine(st0, st1, groups, eps, gamma, beta):
+    s0, q0, V0 = st0
+    B, C0 = s0.shape
+    if st1 is not None:
+        s1, q1, V1 = st1
+        C1 = s1.shape[1]
+        rep = V0 // V1
+    else:
+        s1 = q1 = None
+        C1, V1, rep = 0, 0, 1
+    a = torch.empty((B, C0 + C1), dtype=torch.float32, device=s0.device)
+    d = torch.empty_like(a)
+    _lib.call("gn_groupnorm_affine", _p(s0), _p(q0), C0, V0, _p(s1), _p(q1), C1, V1, rep, B, groups, float(eps), _p(gamma), _p(beta),
+              _p(a), _p(d), _stream())
+    return a, d
+
+
+def conv3d_gcr(src0, src1, a, d, wp, cout, relu=True):
+    B, D, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[-1]
+    out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
+    _lib.call("gn_conv3d_gcr", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(wp), B, D, H, W, cout, 1 if relu else 0, _p(out), _stream())
+    return out
+
+
+def maxpool3d_2(x):
+    B, D, H, W, C = x.shape
+    out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    _lib.call("gn_maxpool3d_2", _p(x), B, D, H, W, C, _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+def trilinear_sample(vol_b, query=None, Q=0, m0=0, M=None, out=None):
+    """vol_b: one sample, channel-last [D][H][W][C].  query [M][3] or lattice rows m0..m0+M of (Q,Q,Q)."""
+    D, H, W, C = vol_b.shape
+    if query is not None:
+        M = query.shape[0]
+        _chk(query, torch.float32, "query")
+    if out is None:
+        out = new_rows(M, C, vol_b.device)
+    _lib.call("gn_trilinear_sample", _p(vol_b), D, H, W, C, _p(query), int(Q), int(m0), int(M), _p(out), rows_view(out)[1], _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ isosurface
+def ggm3d(vol, sigma):
+    _chk(vol, torch.float32, "vol")
+    n0, n1, n2 = vol.shape
+    tmp = torch.empty((2,) + tuple(vol.shape), dtype=torch.float32, device=vol.device)
+    out = torch.empty_like(vol)
+    _lib.call("gn_ggm3d", _p(vol), n0, n1, n2, float(sigma), _p(tmp), _p(out), _stream())
+    return out
+
+
+def minmax(x):
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.call("gn_minmax", _p(_chk(x, torch.float32, "x")), x.numel(), _p(out), _stream())
+    return out
+
+
+def mc33(vol, level, cap_v, cap_f):
+    """-> verts_vox [cap_v][3], faces [cap_f][3], normals, values, counts (device int64 [2] = V, F)"""
+    _chk(vol, torch.float32, "vol")
+    n0, n1, n2 = vol.shape
+    dev = vol.device
+    nbytes = _lib.load().gn_mc33_workspace_bytes(n0, n1, n2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    verts = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((cap_f, 3), dtype=_i32, device=dev)
+    normals = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
+    values = torch.empty(cap_v, dtype=torch.float32, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    _lib.call("gn_mc33", _p(vol), n0, n1, n2, float(level), _p(ws), nbytes, _p(verts), _p(faces), _p(normals), _p(values), cap_v, cap_f,
+              _p(counts), _stream())
+    return verts, faces, normals, values, counts
+
+
+def gather_nn(vol, verts_vox, spacing):
+    nv = verts_vox.shape[0]
+    out = torch.empty(nv, dtype=torch.float32, device=vol.device)
+    _lib.call("gn_gather_nn", _p(vol), *vol.shape, _p(verts_vox), nv, float(spacing), _p(out), _stream())
+    return out
+
+
+def scale_verts(verts_vox, spacing):
+    out = torch.empty_like(verts_vox)
+    _lib.call("gn_scale_verts", _p(verts_vox), verts_vox.shape[0], float(spacing), _p(out), _stream())
+    return out

@@ -1,0 +1,127 @@
+"""Drop-in for the compute slice of /root/reference/predict.py:138-209.
+
+``predict_batch`` runs, for every garment of a batch, exactly the reference's stages
+    pointnet2_forward -> unet3d_forward -> (Q,Q,Q) WNF decode -> gaussian_gradient_magnitude -> marching cubes (Lewiner)
+    -> nearest-voxel GGM at the vertices -> surface_decoder_forward (warp field) [-> mc_surface_decoder (hole head)]
+entirely on the GPU; a ValueError from marching cubes (level outside the volume range) yields the reference's NaN
+placeholder mesh (predict.py:165-171,188-189).  Results stay on the device; ``to_host`` converts one result to the
+numpy dict predict.py writes to zarr (predict.py:191-209).
+
+The CLI reproduces the reference's config keys (config/predict_default.yaml: main.gpu_id, prediction.volume_size,
+gradient_sigma, iso_surface_level, gradient_direction, use_hole_prediction) with argparse; dataset / zarr / wandb I/O
+is out of scope, so inputs are a checkpoint (or seeded synthetic weights) and synthetic clouds.
+"""
+import argparse
+import json
+import time
+
+import numpy as np
+import torch
+
+from . import synthetic
+from .batch import Batch
+from .common import marching_cubes_util as mcu
+from .common.torch_util import to_numpy
+from .networks.conv_implicit_wnf import ConvImplicitWNFPipeline
+
+
+def nan_placeholder(device):
+    """predict.py:165-170"""
+    nan3 = torch.full((1, 3), float("nan"), device=device)
+    return dict(verts=nan3.double(), verts_f32=nan3.clone(), faces=torch.zeros((1, 3), dtype=torch.int32, device=device),
+                normals=nan3.clone(), volume_value=torch.full((1,), float("nan"), device=device),
+                volume_gradient_magnitude=torch.full((1,), float("nan"), device=device), warp_field=nan3.clone())
+
+
+def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
+                  use_hole_prediction=False, auto_level=False):
+    """-> list (one per garment) of dicts of device tensors."""
+    with torch.no_grad():
+        pointnet2_result = model.pointnet2_forward(batch)
+        unet3d_result = model.unet3d_forward(pointnet2_result)
+        vol = unet3d_result["out_feature_volume"]
+        nocs_data = pointnet2_result["nocs_data"]
+        B = vol.shape[0]
+        wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
+        ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
+        results = []
+        for b in range(B):
+            wnf = wnf_all[b]
+            res = dict(wnf_volume=wnf)
+            level = iso_surface_level
+            if auto_level:
+                mm = torch.stack([wnf.min(), wnf.max()]).cpu()
+                level = 0.5 * (float(mm[0]) + float(mm[1]))
+            try:
+                mesh = mcu.wnf_to_mesh_gpu(wnf, level, gradient_sigma, gradient_direction)
+                u3_b = {"out_feature_volume": vol[b:b + 1]}
+                q = mesh["verts_f32"].view(1, -1, 3)
+                mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
+                if use_hole_prediction:
+                    logits = model.mc_surface_decoder_forward(u3_b, q)["out_features"].reshape(-1)
+                    mesh["is_on_surface_logits"] = logits
+                    mesh["is_on_surface"] = logits > 0
+                mesh.pop("ggm", None)
+                res.update(mesh)
+            except ValueError:
+                res.update(nan_placeholder(vol.device))
+            sl = slice(int(ptr[b]), int(ptr[b + 1]))
+            res.update(pred_nocs=nocs_data.pos[sl], pred_nocs_confidence=nocs_data.pred_confidence[sl],
+                       pred_nocs_logits=pointnet2_result["per_point_logits"][sl])
+            results.append(res)
+        return results
+
+
+def to_host(res):
+    """numpy dict with the dtypes predict.py:191-199 writes."""
+    out = {
+        "verts": to_numpy(res["verts"]).astype(np.float32), "faces": to_numpy(res["faces"]).astype(np.int32),
+        "normals": to_numpy(res["normals"]).astype(np.float32), "volume_value": to_numpy(res["volume_value"]).astype(np.float32),
+        "volume_gradient_magnitude": to_numpy(res["volume_gradient_magnitude"]).astype(np.float32),
+        "warp_field": to_numpy(res["warp_field"]).astype(np.float32),
+    }
+    for k in ("is_on_surface", "is_on_surface_logits"):
+        if k in res:
+            out[k] = to_numpy(res[k])
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="GarmentNets predict (MI355X-native), synthetic-input mode")
+    ap.add_argument("--checkpoint_path", default=None, help="Lightning-style .ckpt; default: seeded synthetic weights")
+    ap.add_argument("--gpu_id", type=int, default=0)
+    ap.add_argument("--volume_size", type=int, default=128)
+    ap.add_argument("--gradient_sigma", type=float, default=0.5)
+    ap.add_argument("--iso_surface_level", type=float, default=0.5)
+    ap.add_argument("--gradient_direction", default="ascent")
+    ap.add_argument("--use_hole_prediction", action="store_true")
+    ap.add_argument("--num_samples", type=int, default=4)
+    ap.add_argument("--num_pc_sample", type=int, default=6000)
+    ap.add_argument("--grid", type=int, default=32)
+    ap.add_argument("--reduce_method", default="max")
+    ap.add_argument("--out", default=None, help="optional .npz with the last mesh")
+    a = ap.parse_args(argv)
+    device = torch.device("cuda:{}".format(a.gpu_id))
+    if a.checkpoint_path:
+        model = ConvImplicitWNFPipeline.load_from_checkpoint(a.checkpoint_path)
+    else:
+        hp = synthetic.default_hparams(grid=a.grid, reduce_method=a.reduce_method, mc_surface=a.use_hole_prediction)
+        model = ConvImplicitWNFPipeline(**hp)
+        model.load_state_dict(synthetic.synthetic_state_dict(hp, 0))
+    model = model.to(device).eval().requires_grad_(False)
+    last = None
+    for i in range(a.num_samples):   # batch_size == 1 as asserted by predict.py:62
+        x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
+        t0 = time.time()
+        res = predict_batch(model, Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch).to(device), a.volume_size,
+                            a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction)[0]
+        last = to_host(res)
+        torch.cuda.synchronize()
+        print(json.dumps({"sample": i, "verts": int(last["verts"].shape[0]), "faces": int(last["faces"].shape[0]),
+                          "seconds": round(time.time() - t0, 4)}))
+    if a.out and last is not None:
+        np.savez_compressed(a.out, **last)
+
+
+if __name__ == "__main__":
+    main()

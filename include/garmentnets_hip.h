@@ -1,0 +1,182 @@
+/*
+ * garmentnets_hip.h -- C ABI of libgarmentnets_hip.so (MI355X / gfx950).
+ *
+ * The reference (real-stanford/garmentnets) is pure Python and has no FFI of its own: its inference hot
+ * path reaches native code only through third-party operator packages.  Each entry point below replaces
+ * ONE such operator call site (cited as reference file:line) with a hand-written HIP kernel; the Python
+ * host (garmentnets_amd/) binds them with ctypes and keeps the reference's module API on top
+ * (INTEGRATION.md shows the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every function returns GN_OK (0) or a negative GN_E* code; gn_last_error() gives a thread-local message.
+ *   - all pointers are DEVICE pointers into caller-owned memory unless the name ends in _host.
+ *   - stream is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered, no
+ *     allocation, no host synchronisation, no global mutable state (LUTs are immutable).
+ *   - dense float tensors are fp32, row-major with an explicit leading dimension (ld*) in elements.
+ *   - volumes are CHANNEL-LAST: [B][D][H][W][C]  (the reference's NCDHW is a host-side view of this).
+ *   - indices: point / vertex indices int32 on device (int64 only where the reference API exposes them).
+ */
+#ifndef GARMENTNETS_HIP_H
+#define GARMENTNETS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_OK 0
+#define GN_EINVAL (-1)   /* bad argument (shape / alignment / unsupported size) */
+#define GN_ELAUNCH (-2)  /* HIP launch error */
+#define GN_ECAP (-3)     /* caller-provided capacity too small (counts are still returned) */
+
+const char *gn_last_error(void);
+int gn_version(void);
+/* number of CUs / XCDs the library sees on the current device (sanity: 256 / 8 on MI355X) */
+int gn_device_info(int *num_cu, int *lds_bytes_per_cu);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Point-set operators (PointNet++).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* ptr[b] = first index i with batch[i] >= b, b = 0..B  (batch sorted ascending, int64).
+ * replaces: PyG Batch bookkeeping used by every segmented op (components/pointnet2.py:26-29). */
+int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *ptr, void *stream);
+
+/* Farthest point sampling.  replaces torch_cluster.fps -- components/pointnet2.py:26.
+ * Per example b (points ptr[b]..ptr[b+1]) emits out_ptr[b+1]-out_ptr[b] indices (GLOBAL point index) starting
+ * with the example's first point; dist = (dx*dx+dy*dy)+dz*dz in fp32 without FMA; ties -> lowest index.
+ * One 1024-thread workgroup per example, positions + running min-distance resident in LDS. */
+int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, int B, int max_points_per_example,
+           int32_t *out_idx, void *stream);
+
+/* Ball query.  replaces torch_cluster.radius(max_num_neighbors=K) -- components/pointnet2.py:28-29.
+ * For every centre c (a point index centre_idx[c], example b): the first K points j of example b in ascending
+ * index with d2(j,c) < r2 (strict).  nbr: [M][K] int32, -1 padded; cnt: [M].  One wavefront per centre
+ * (ballot + popcount prefix keep the ascending order). */
+int gn_ball_query(const float *pos, const int32_t *ptr, const int32_t *centre_idx, const int32_t *centre_ptr, int B,
+                  int M, float r2, int K, int32_t *nbr, int32_t *cnt, void *stream);
+
+/* Edge-feature gather for PointConv.  replaces PyG PointConv.message() gather -- components/pointnet2.py:31.
+ * Row (c*(K+1)+s) of out = [x[j] (C floats), pos[j]-pos[centre_idx[c]] (3 floats)] for slot s of centre c, where
+ * slots 0..K-1 are nbr[c][s] with the PointConv self-loop rule applied (a neighbour whose index equals the
+ * centre ORDINAL c is dropped) and slot K is point c itself (add_self_loops on the bipartite graph);
+ * self_loops=0 disables both.  Invalid slots are written as zeros and slot_src[c*(K+1)+s] = -1.
+ * x may be NULL (C=0). */
+int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                 int M, int K, int self_loops, float *out, int ldo, int32_t *slot_src, void *stream);
+
+/* out[c][ch] = max over valid slots s of in[c*S+s][ch].  replaces PointConv aggr='max' (scatter-max). */
+int gn_segment_max(const float *in, int ldi, const int32_t *slot_src, int M, int S, int C, float *out, int ldo,
+                   void *stream);
+
+/* out[b][ch] = max over rows ptr[b]..ptr[b+1].  replaces PyG global_max_pool -- components/pointnet2.py:49. */
+int gn_global_max_pool(const float *in, int ldi, const int32_t *ptr, int B, int C, float *out, int ldo, void *stream);
+
+/* k-NN inverse-squared-distance interpolation.  replaces PyG knn_interpolate -- components/pointnet2.py:72.
+ * k <= 8; neighbours ordered by ascending (d2, index); w = 1/max(d2,1e-16); out = sum(w x)/sum(w). */
+int gn_knn_interpolate(const float *xs, int ldx, const float *ps, const int32_t *ptr_s, const float *pq,
+                       const int32_t *ptr_q, int B, int Nq, int C, int k, float *out, int ldo, void *stream);
+
+/* Dense layer:  Y = bn( act( X W^T + bias ) ),  X [M][K] (ldx), W [N][K] (ldw), Y [M][N] (ldy).
+ * relu != 0 applies ReLU; bn_scale/bn_shift (may be NULL) apply y*scale[n]+shift[n] AFTER the ReLU
+ * (components/mlp.py:9-20: Linear -> ReLU -> BatchNorm1d in eval mode).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * replaces torch.nn.Linear / ReLU / BatchNorm1d (ATen addmm + batch_norm) -- components/mlp.py:9-20,
+ * networks/pointnet2_nocs.py:145-157, and the 1x1x1 final_conv components/unet3d.py:437,467. */
+int gn_linear(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *bn_scale,
+              const float *bn_shift, int relu, int64_t M, int N, int K, float *Y, int ldy, void *stream);
+
+/* NOCS head post-processing.  replaces argmax/softmax/gather + VirtualGrid.idxs_to_points --
+ * networks/conv_implicit_wnf.py:220-231.  logits [N][bins*3] viewed as [N][bins][3]. */
+int gn_nocs_head(const float *logits, int ldl, int64_t N, int bins, int64_t *bin_idx /*[N][3]*/, float *confidence /*[N][3]*/,
+                 float *pred_nocs /*[N][3]*/, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Gridding (VolumeFeatureAggregator).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Per-point aggregation features + target cell.  replaces VirtualGrid.get_points_grid_idxs / flatten_idxs /
+ * idxs_to_points + torch.cat -- networks/conv_implicit_wnf.py:72-85, components/gridding.py:161-256.
+ * out row = [feat (Cf), p - cell_corner (3), sim_pos (3), confidence (3)];  flat = ((b*G0+ix)*G1+iy)*G2+iz. */
+int gn_grid_features(const float *feat, int ldf, int Cf, const float *nocs, const float *sim_pos, const float *conf,
+                     const int64_t *batch, int64_t N, const float lower[3], const float upper[3], const int grid[3],
+                     int include_point, int include_conf, float *out, int ldo, int32_t *flat_idx, void *stream);
+
+/* Scatter point features into a zero-filled channel-last volume.  replaces torch_scatter.scatter(reduce) --
+ * networks/conv_implicit_wnf.py:92-94.  reduce: 0 = max, 1 = mean.  vol [cells][C] must be zeroed by this
+ * call (it does the memset); count_ws: [cells] int32 workspace.  Empty cells stay 0. */
+int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
+                    float *vol, int32_t *count_ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3-D UNet (channel-last volumes [B][D][H][W][C]).
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Per-(sample, channel) sum and sum of squares over the V voxels, fp64 accumulators [B][C] (zeroed inside).
+ * First half of nn.GroupNorm -- components/unet3d.py:66. */
+int gn_channel_stats(const float *x, int B, int64_t V, int C, double *sum, double *sumsq, void *stream);
+
+/* GroupNorm statistics -> per-(sample, channel) affine  y = x*a + d  for the concatenation of up to two
+ * sources (src0: C0 channels, V0 voxels; src1: C1 channels, V1 voxels each replicated rep1 times = nearest
+ * upsampling).  groups over C0+C1 channels, eps, biased variance (nn.GroupNorm).  a,d: [B][C0+C1]. */
+int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0, int64_t V0, const double *sum1, const double *sq1,
+                        int C1, int64_t V1, int rep1, int B, int groups, float eps, const float *gamma,
+                        const float *beta, float *a, float *d, void *stream);
+
+/* Fused GroupNorm-apply + Conv3d(3x3x3, pad 1, no bias) + ReLU, the 'gcr' SingleConv --
+ * components/unet3d.py:53-66,19-76.  Input = channel concatenation [src0 (C0 ch, full res), src1 (C1 ch, HALF
+ * res, nearest-upsampled on the fly)] (torch.cat((skip, up(x))) of components/unet3d.py:291,330); src1 may be
+ * NULL.  Zero padding is applied AFTER the affine (as nn.Conv3d pads the normalised tensor).
+ * wp: weights repacked [27][Cin][Cout] (tap = (kd*3+kh)*3+kw).  LDS-tiled implicit GEMM on fp32 MFMA. */
+int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
+                  const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, void *stream);
+
+/* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C]. */
+int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Implicit decoder.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Trilinear feature sampling.  replaces F.grid_sample(bilinear, border, align_corners=True) on a 5-D input --
+ * networks/conv_implicit_wnf.py:135-145 (including its axis convention: query x -> LAST volume axis).
+ * vol: one sample [D][H][W][C].  If query == NULL the queries are the lattice of predict.py:145-147:
+ * q[i][j][k] = (i,j,k) * (1/(Q-1)), rows m0..m0+M of the flattened (Q,Q,Q) lattice. */
+int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const float *query, int Q, int64_t m0, int64_t M,
+                        float *out, int ldo, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Isosurface.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Gaussian gradient magnitude (sigma, mode='nearest').  replaces scipy.ndimage.gaussian_gradient_magnitude --
+ * predict.py:162-163.  tmp: 2 volumes of workspace. Bit-compatible accumulation order (fp64 taps, fp32 stores). */
+int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream);
+
+/* min / max of a float array (device result [2]); level-range check of skimage marching_cubes. */
+int gn_minmax(const float *x, int64_t n, float *out2, void *stream);
+
+/* Lewiner marching cubes (MC33).  replaces skimage.measure.marching_cubes(method='lewiner') -- predict.py:172-177.
+ * gn_mc33_workspace_bytes: bytes of `ws` for a volume of n0*n1*n2.
+ * gn_mc33: classify + scan + emit.  verts [cap_v][3] float32 (array-axis order, voxel units), faces [cap_f][3]
+ * int32 ('ascent' orientation), normals [cap_v][3], values [cap_v]; counts_dev[2] = {V, F} (device int64) are
+ * always written; entries beyond the capacities are dropped (caller re-runs with larger buffers). */
+size_t gn_mc33_workspace_bytes(int n0, int n1, int n2);
+int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+            int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev,
+            void *stream);
+
+/* out[i] = vol[(uint32)(verts[i]/spacing)] (float64 division, truncation) -- predict.py:179-181.
+ * verts_vox: float32 voxel-unit vertices as produced by gn_mc33; spacing applied in fp64 as numpy does. */
+int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
+                 float *out, void *stream);
+
+/* verts_out[i] = (float)((double)verts_vox[i] * spacing): the float32 query points predict.py:184 feeds to the
+ * surface decoder (mc_verts.astype(np.float32)). */
+int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *verts_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GARMENTNETS_HIP_H */

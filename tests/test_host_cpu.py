@@ -1,0 +1,104 @@
+"""CPU: host-side logic of the product package (no kernel is launched): C-ABI symbol table, checkpoint schema,
+VirtualGrid / ArraySlicer against the reference goldens, Batch bookkeeping."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from garmentnets_amd import _lib, ops, synthetic as S
+from garmentnets_amd.batch import Batch
+from garmentnets_amd.components.gridding import ArraySlicer, VirtualGrid
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "garmentnets_hip.h")).read()
+    declared = set(re.findall(r"\b(gn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/garmentnets_hip.h but not exported"
+    assert declared - {"gn_last_error"} == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with the header"
+    assert lib.gn_version() >= 100
+
+
+def test_invalid_arguments_fail_loudly_without_gpu():
+    # argument validation happens before any launch, so it can be exercised on a CPU-only box
+    with pytest.raises(ValueError):
+        _lib.call("gn_linear", None, 4, None, 4, None, None, None, 0, 8, 0, 4, None, 4, None)   # N == 0
+    with pytest.raises(ValueError):
+        _lib.call("gn_conv3d_gcr", None, 17, None, 0, None, None, None, 1, 8, 8, 8, 32, 1, None, None)   # Cin % 16
+    with pytest.raises(ValueError):
+        _lib.call("gn_knn_interpolate", None, 4, None, None, None, None, 1, 1, 4, 9, None, 4, None)   # k > 8
+    assert "k must be" in _lib.load().gn_last_error().decode()
+
+
+def test_cpu_tensors_are_rejected():
+    with pytest.raises(_lib.GarmentNetsHipError):
+        ops.minmax(torch.zeros(8))
+
+
+def test_checkpoint_schema_matches_reference_dump():
+    from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
+    hp = S.default_hparams()
+    model = ConvImplicitWNFPipeline(**hp)
+    sd = model.state_dict()
+    spec = dict(S.state_dict_spec(hp))
+    assert set(sd) == set(spec) and len(sd) == 222                       # 222 tensors
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in sd)
+    n_params = sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    assert n_params == 7552248
+    hp2 = S.default_hparams(mc_surface=True)
+    assert any(k.startswith("mc_surface_decoder.") for k in ConvImplicitWNFPipeline(**hp2).state_dict())
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
+    hp = S.default_hparams(grid=8)
+    m = ConvImplicitWNFPipeline(**hp)
+    m.load_state_dict(S.synthetic_state_dict(hp, 3))
+    p = tmp_path / "x.ckpt"
+    m.save_checkpoint(str(p))
+    m2 = ConvImplicitWNFPipeline.load_from_checkpoint(str(p))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+
+
+def test_virtual_grid_against_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_gridding.npz"))
+    bins = torch.arange(64).unsqueeze(1).repeat(1, 3)
+    nocs = VirtualGrid(grid_shape=(64,) * 3, batch_size=1).idxs_to_points(bins)
+    assert np.array_equal(nocs.numpy(), g["nocs_of_bin"])
+    for G in (8, 16, 32, 128):
+        vg = VirtualGrid(grid_shape=(G,) * 3, batch_size=2)
+        cells = vg.get_points_grid_idxs(nocs)
+        assert np.array_equal(cells.numpy(), g[f"cell_of_bin_{G}"])
+        assert np.array_equal(vg.idxs_to_points(cells).numpy(), g[f"corner_of_bin_{G}"])
+    vg = VirtualGrid(grid_shape=(32, 32, 32), batch_size=2)
+    idx = vg.get_points_grid_idxs(torch.from_numpy(g["rand_pts"]), batch_idx=torch.from_numpy(g["rand_batch"]))
+    assert np.array_equal(idx.numpy(), g["rand_idx"])
+    flat = vg.flatten_idxs(idx)
+    assert np.array_equal(flat.numpy(), g["rand_flat"])
+    assert np.array_equal(vg.unflatten_idxs(flat).numpy(), g["rand_idx"])
+    assert np.array_equal(VirtualGrid(grid_shape=(5,) * 3).get_grid_points(include_batch=False).numpy(), g["grid_points_5"])
+    assert vg.num_grids == 2 * 32 ** 3
+
+
+def test_array_slicer_against_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_gridding.npz"))
+    for shape, chunks in (((128, 128, 128, 3), (64, 64, 64)), ((70, 64, 10, 3), (64, 64, 64))):
+        sl = ArraySlicer(shape, chunks)
+        got = np.array([[(s.start, s.stop) for s in sl[i]] for i in range(len(sl))], np.int64)
+        assert np.array_equal(got, g["slicer_%d" % shape[0]])
+        assert len(list(sl)) == len(sl)
+
+
+def test_batch_and_fps_count():
+    b = Batch(x=torch.zeros(5, 3), batch=torch.tensor([0, 0, 1, 1, 1]))
+    assert b.num_graphs == 2 and b.sizes == [2, 3]
+    assert Batch(sizes=[4, 4], batch=torch.zeros(8, dtype=torch.int64)).num_graphs == 2
+    assert ops.fps_count(6000, 0.5) == 3000 and ops.fps_count(3000, 0.25) == 750 and ops.fps_count(7, 0.5) == 4
+    assert ops.fps_count(1, 0.25) == 1
