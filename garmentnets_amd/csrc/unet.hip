@@ -6,6 +6,7 @@
 // Reference: /root/reference/components/unet3d.py:19-144 (create_conv / SingleConv / DoubleConv 'gcr'),
 // :195-330 (Encoder / Decoder / Upsampling), :449-474 (forward).
 #include "common.h"
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -264,6 +265,17 @@ __global__ __launch_bounds__(256) void conv3d_gcr_kernel(ConvArgs p) {
     }
 }
 
+// tuning knob (gn_set_tunable("conv_nt4", 0|1)): use the 128-wide output-channel tile for Cout % 128 == 0.
+// Measured on MI355X (profiles/r01_ab_conv_tile.txt): the 64-wide tile (96 accumulator registers, 2 waves/SIMD) runs at
+// 128 TFLOP/s, the 128-wide one (304 registers, 1 wave/SIMD, spills) at 93 TFLOP/s -> default off.
+static int g_conv_nt4 = 0;
+extern "C" int gn_set_tunable(const char *name, int value) {
+    if (!name) return GN_EINVAL;
+    if (!strcmp(name, "conv_nt4")) { g_conv_nt4 = value; return GN_OK; }
+    gn_set_error("gn_set_tunable: unknown tunable %s", name);
+    return GN_EINVAL;
+}
+
 extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                              const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr: bad sizes");
@@ -279,7 +291,7 @@ extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C
     p.tiles_x = (int)gn_cdiv(W, CV_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
     hipStream_t st = gn_stream(stream);
-    if (Cout % 128 == 0) hipLaunchKernelGGL(conv3d_gcr_kernel<4>, dim3(tiles, Cout / 128, B), dim3(256), 0, st, p);
+    if (Cout % 128 == 0 && g_conv_nt4) hipLaunchKernelGGL(conv3d_gcr_kernel<4>, dim3(tiles, Cout / 128, B), dim3(256), 0, st, p);
     else if (Cout % 64 == 0) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
     GN_LAUNCH_CHECK("gn_conv3d_gcr");

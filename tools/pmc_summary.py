@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into per-kernel HBM traffic.
+
+usage: tools/pmc_summary.py <dir_with_FETCH_SIZE_csv> <dir_with_WRITE_SIZE_csv> <steps_in_run> > profiles/rNN_conv_traffic.json
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly 1/2 of the bytes of coalesced streaming reads ->
+doubled; calibrated here on channel_stats_kernel, whose traffic is known exactly (reads every element once)."""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[name][0] += 1
+        agg[name][1] += float(r["Counter_Value"])
+    return agg
+
+
+fetch = load(sys.argv[1] + "/pmc_counter_collection.csv")
+write = load(sys.argv[2] + "/pmc_counter_collection.csv")
+out = {"units": "bytes per launch (average over the run)", "fetch_correction": 2.0, "kernels": {}}
+for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+    if fetch[k][1] < 1024:
+        continue
+    n = fetch[k][0]
+    f = 2.0 * fetch[k][1] * 1024 / n
+    w = write.get(k, [n, 0.0])[1] * 1024 / n
+    out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
+json.dump(out, sys.stdout, indent=1)
