@@ -103,16 +103,13 @@ def cpu_baseline(args, hp, sd):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from garmentnets_amd import parallel
+    rank, local_rank, world = parallel.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+    parallel.init(backend="nccl", device=dev)      # "nccl" is RCCL on ROCm; no-op for one process
 
     from garmentnets_amd import synthetic as S
     from garmentnets_amd.batch import Batch
@@ -142,30 +139,24 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    parallel.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
     verts_total = sum(int(r["verts"].shape[0]) for r in res)
     assert not any(bool(torch.isnan(r["verts"]).any()) for r in res), "marching cubes produced a placeholder mesh"
 
-    times = [dt]
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)                      # the only collective: per-rank metrics over RCCL/xGMI
-        times = [float(v) for v in allt]
+    # the only collective: per-rank (garments, seconds) over RCCL/xGMI
+    per_rank = parallel.gather_metrics([args.batch * args.steps, dt], device=dev)
     if rank == 0:
-        tmax = max(times)
+        value, tmax = parallel.aggregate_throughput(per_rank)
         garments = args.batch * world * args.steps
         groups = timer.summary()
         key = max(groups, key=lambda k: groups[k]["ms"])
@@ -194,7 +185,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, hp, sd)
         print(json.dumps(line))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

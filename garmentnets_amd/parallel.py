@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing: one process per GPU, garments sharded contiguously, NO data-path collective.
+
+The path shards by garment: every op is segmented by example and the 30 MB of weights are replicated, so
+garment batches never move between GPUs.  The only collective is an all-gather of a small fixed-size metrics vector per
+rank (RCCL over xGMI on GPUs, gloo in the CPU tests) -- latency-bound, bandwidth irrelevant.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+METRIC_SLOTS = 8   # [garments, seconds, + 6 spare per-stage slots]
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" IS RCCL on ROCm
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend=backend, **kw)
+    return rank, local_rank, world
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo, hi) of `total` garments owned by `rank`; remainders go to the lowest ranks."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def gather_metrics(values, device="cpu"):
+    """all-gather a short list of floats from every rank -> list (per rank) of lists."""
+    v = list(values) + [0.0] * (METRIC_SLOTS - len(values))
+    assert len(v) == METRIC_SLOTS
+    t = torch.tensor(v, dtype=torch.float64, device=device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def aggregate_throughput(per_rank):
+    """per_rank: [[garments, seconds, ...], ...] -> (whole-job garments/s with the MAX time over ranks, max seconds)."""
+    garments = sum(r[0] for r in per_rank)
+    tmax = max(r[1] for r in per_rank)
+    return garments / tmax, tmax

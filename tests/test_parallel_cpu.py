@@ -1,0 +1,61 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of bench.py (garment sharding + the metrics all-gather)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from garmentnets_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = parallel.init(backend="gloo")
+    lo, hi = parallel.shard_range(total, r, w)
+    parallel.barrier()
+    per_rank = parallel.gather_metrics([hi - lo, 1.0 + 0.5 * r], device="cpu")      # rank 1 is the slow one
+    value, tmax = parallel.aggregate_throughput(per_rank)
+    q.put((r, lo, hi, per_rank, value, tmax))
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_ranges_cover_and_balance():
+    for total in (0, 1, 7, 16, 128, 129):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert parallel.shard_range(128, 3, 8) == (48, 64)       # BASELINE config 4: 16 garments per GPU
+
+
+def test_two_rank_gloo_metrics_gather():
+    world, total = 2, 33
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, pr0, v0, t0), (r1, lo1, hi1, pr1, v1, t1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 17, 17, 33)
+    assert pr0 == pr1 and [p[0] for p in pr0] == [17.0, 16.0] and [p[1] for p in pr0] == [1.0, 1.5]
+    assert v0 == v1 == 33 / 1.5 and t0 == 1.5        # whole-job garments / MAX time over ranks
+
+
+def test_single_process_passthrough():
+    assert parallel.gather_metrics([4, 2.0]) == [[4.0, 2.0] + [0.0] * 6]
+    assert parallel.aggregate_throughput([[4, 2.0]]) == (2.0, 2.0)
