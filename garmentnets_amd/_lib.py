@@ -35,6 +35,8 @@ PROTOTYPES = {
     "gn_conv3d_gcr": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_trilinear_sample": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i32, _vp],
+    "gn_implicit_decode": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
+                           _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "gn_ggm3d": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
     "gn_minmax": [_vp, _i64, _vp, _vp],
     "gn_mc33_workspace_bytes": [_i32, _i32, _i32],

@@ -49,6 +49,21 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
         ok[c] = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
         off[c] = (((int64_t)zz * H + yy) * W + xx) * C;
     }
+    if ((C & 1) == 0) {
+        // two channels per lane: one 8-byte load per corner per lane, 512 contiguous bytes per wave for C = 128
+        for (int ch = lane * 2; ch < C; ch += 128) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (ok[c]) {
+                    const float2 v = *reinterpret_cast<const float2 *>(vol + off[c] + ch);
+                    acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, wgt[c]));
+                    acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, wgt[c]));
+                }
+            *reinterpret_cast<float2 *>(out + m * ldo + ch) = acc;
+        }
+        return;
+    }
     for (int ch = lane; ch < C; ch += 64) {
         float acc = 0.f;
 #pragma unroll
@@ -62,9 +77,202 @@ extern "C" int gn_trilinear_sample(const float *vol, int D, int H, int W, int C,
                                    float *out, int ldo, void *stream) {
     GN_REQUIRE(D > 0 && H > 0 && W > 0 && C > 0 && M >= 0 && ldo >= C, "gn_trilinear_sample: bad sizes");
     GN_REQUIRE(query != nullptr || (Q > 1 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_trilinear_sample: bad lattice range");
+    GN_REQUIRE((C & 1) || (ldo % 2 == 0), "gn_trilinear_sample: even channel counts need an even output leading dimension");
     if (M == 0) return GN_OK;
     hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gn_cdiv(M, 4)), dim3(256), 0, gn_stream(stream), vol, D, H, W, C, query, Q, m0, M,
                        out, ldo);
     GN_LAUNCH_CHECK("gn_trilinear_sample");
+    return GN_OK;
+}
+
+// ================================================================================================ fused implicit decoder
+// gn_implicit_decode: trilinear sample -> Linear/ReLU/BN (C0 -> N1) -> Linear/ReLU/BN (N1 -> N2) -> Linear/ReLU/BN (N2 -> OUT<=4)
+// in ONE kernel (ImplicitWNFDecoder.forward, networks/conv_implicit_wnf.py:128-149 with MLP [128,256,256,out]).
+//
+// Block = 256 threads (4 waves) = 32 queries.  Activations never leave the CU: the sampled features X0 [32][C0], H1 [32][N1]
+// and H2 [32][N2] live in LDS (row stride odd -> the 32 rows of an MFMA A fragment hit 32 distinct banks); two regions are
+// ping-ponged (P: X0 then H2, Q: H1) = 66 KB for [128,256,256] -> 2 workgroups per CU, so one samples while the other feeds
+// the matrix cores.  The weights (394 KB, L2-resident) are NOT staged through LDS: they are pre-packed k-pair-major
+// Wp[k/16][n][2][8] (see dec_layer), so the B operands of 8 consecutive MFMAs are two coalesced 16-byte loads per lane,
+// register double-buffered one 16-deep k-group ahead.  Each wave owns 64 output columns of a
+// 256-column block (2 column fragments x 1 row fragment = 32 accumulator registers).
+typedef float f32x16d __attribute__((ext_vector_type(16)));
+
+struct DecodeArgs {
+    const float *vol; int D, H, W, C0;
+    const float *xin; int ldxin;          // optional pre-sampled features [M][C0] (then vol/query are unused)
+    const float *query; int Q; long long m0, M;
+    const float *w1p, *b1, *s1, *t1; int N1;
+    const float *w2p, *b2, *s2, *t2; int N2;
+    const float *w3, *b3, *s3, *t3; int OUT;
+    float *out; int ldo;
+};
+
+#define DEC_TM 32
+
+// one dense layer on the 32 resident rows: Y[32][N] = bn(relu(X[32][K] W^T + b)), X and Y in LDS (row stride K+4 / N+4
+// floats: 16-byte aligned rows whose 16-byte slots rotate with the row -> conflict-free ds_read_b128).
+// K is consumed in groups of 16 with a PERMUTED k order (the sum is order-free up to rounding): lanes 0-31 supply
+// k = 16g+j, lanes 32-63 k = 16g+8+j for MFMA j = 0..7, so each lane reads 8 CONSECUTIVE floats of its row (2 x b128) per
+// group, and the matching B values come from the pack Wp[g][n][h][j] = W[n][16g+8h+j]: 32 contiguous bytes per lane, 2 KB
+// contiguous per wave (2 x global_load_dwordx4 per column fragment per group).  Register double-buffering: group g+1 is
+// in flight while the 16 MFMAs of group g issue.
+struct BFrag { float4 lo, hi; };
+
+__device__ __forceinline__ void dec_mfma8(const float4 &a0, const float4 &a1, const BFrag &b0, const BFrag &b1, f32x16d &acc0, f32x16d &acc1) {
+#define DEC_STEP(A, B0, B1)                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B0, acc0, 0, 0, 0);        \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B1, acc1, 0, 0, 0);
+    DEC_STEP(a0.x, b0.lo.x, b1.lo.x) DEC_STEP(a0.y, b0.lo.y, b1.lo.y) DEC_STEP(a0.z, b0.lo.z, b1.lo.z) DEC_STEP(a0.w, b0.lo.w, b1.lo.w)
+    DEC_STEP(a1.x, b0.hi.x, b1.hi.x) DEC_STEP(a1.y, b0.hi.y, b1.hi.y) DEC_STEP(a1.z, b0.hi.z, b1.hi.z) DEC_STEP(a1.w, b0.hi.w, b1.hi.w)
+#undef DEC_STEP
+}
+
+__device__ __forceinline__ void dec_layer(const float *__restrict__ X, int ldx, int K, const float *__restrict__ Wp, const float *__restrict__ bias,
+                                          const float *__restrict__ sc, const float *__restrict__ sh, int N, float *__restrict__ Y, int ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    const float4 *xrow = reinterpret_cast<const float4 *>(X + r * ldx + 8 * h);   // + 4*g float4 per group
+    const int ng = K >> 4;                                                          // even (K % 32 == 0)
+    const size_t gstride = (size_t)N * 4;                                           // float4 per k-group of the pack
+    for (int nb = 0; nb < N; nb += 256) {
+        const int n0 = nb + wave * 64;
+        f32x16d acc0, acc1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
+        const float4 *w0 = reinterpret_cast<const float4 *>(Wp) + ((size_t)(n0 + r) * 2 + h) * 2;   // column fragment 0
+        const float4 *w1 = w0 + 32 * 2 * 2;                                                          // column fragment 1 (n + 32)
+        BFrag c0, c1, d0, d1;
+        c0.lo = w0[0]; c0.hi = w0[1]; c1.lo = w1[0]; c1.hi = w1[1];
+        for (int g = 0; g < ng; g += 2) {
+            {   // prefetch group g+1 into d*, compute group g from c*
+                const float4 *p0 = w0 + (size_t)(g + 1) * gstride, *p1 = w1 + (size_t)(g + 1) * gstride;
+                d0.lo = p0[0]; d0.hi = p0[1]; d1.lo = p1[0]; d1.hi = p1[1];
+                const float4 a0 = xrow[4 * g], a1 = xrow[4 * g + 1];
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMA group (hipcc sinks it otherwise)
+                dec_mfma8(a0, a1, c0, c1, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // prefetch group g+2 into c*, compute group g+1 from d*
+                const int gn = (g + 2 < ng) ? g + 2 : g + 1;
+                const float4 *p0 = w0 + (size_t)gn * gstride, *p1 = w1 + (size_t)gn * gstride;
+                c0.lo = p0[0]; c0.hi = p0[1]; c1.lo = p1[0]; c1.hi = p1[1];
+                const float4 a0 = xrow[4 * (g + 1)], a1 = xrow[4 * (g + 1) + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                dec_mfma8(a0, a1, d0, d1, acc0, acc1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + u * 32 + r;
+            const float bv = bias[n], scv = sc ? sc[n] : 1.f, shv = sh ? sh[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                float v = __fadd_rn(u == 0 ? acc0[q] : acc1[q], bv);
+                v = fmaxf(v, 0.f);
+                if (sc) v = __fadd_rn(__fmul_rn(v, scv), shv);
+                Y[row * ldy + n] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void implicit_decode_kernel(DecodeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ldp = (p.C0 > p.N2 ? p.C0 : p.N2) + 4, ldq = p.N1 + 4;
+    float *P = dsm, *Qb = dsm + DEC_TM * ldp;
+    const long long mb = (long long)blockIdx.x * DEC_TM;
+    // ---- phase 0: X0 = pre-sampled rows (coalesced 16-byte loads) or trilinear sampling of 8 queries per wave
+    if (p.xin) {
+        const int c4n = p.C0 >> 2;
+        for (int idx = threadIdx.x; idx < DEC_TM * c4n; idx += 256) {
+            const int row = idx / c4n, c4 = idx % c4n;
+            long long m = mb + row;
+            if (m >= p.M) m = p.M - 1;
+            *reinterpret_cast<float4 *>(P + row * ldp + c4 * 4) = *reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + c4 * 4);
+        }
+    } else
+    for (int qi = 0; qi < DEC_TM / 4; ++qi) {
+        const int row = wave * (DEC_TM / 4) + qi;
+        long long m = mb + row;
+        if (m >= p.M) m = p.M - 1;   // tail rows recompute the last query; never stored
+        float qx, qy, qz;
+        if (p.query) {
+            qx = p.query[m * 3]; qy = p.query[m * 3 + 1]; qz = p.query[m * 3 + 2];
+        } else {
+            const long long g = p.m0 + m;
+            const int k = (int)(g % p.Q), j = (int)((g / p.Q) % p.Q), i = (int)(g / ((long long)p.Q * p.Q));
+            const float sc = __fdiv_rn(1.0f, __fsub_rn((float)p.Q, 1.0f));
+            qx = __fadd_rn(__fmul_rn((float)i, sc), -0.0f);
+            qy = __fadd_rn(__fmul_rn((float)j, sc), -0.0f);
+            qz = __fadd_rn(__fmul_rn((float)k, sc), -0.0f);
+        }
+        const float ix = src_index(qx, p.W), iy = src_index(qy, p.H), iz = src_index(qz, p.D);
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+        const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        const float wz1 = __fsub_rn(iz, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+        for (int ch = lane; ch < p.C0; ch += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+                if (xx < p.W && yy < p.H && zz < p.D) {   // lower bounds hold after the border clamp
+                    const float wgt = __fmul_rn(__fmul_rn(dx ? wx1 : wx0, dy ? wy1 : wy0), dz ? wz1 : wz0);
+                    acc = __fadd_rn(acc, __fmul_rn(p.vol[(((long long)zz * p.H + yy) * p.W + xx) * p.C0 + ch], wgt));
+                }
+            }
+            P[row * ldp + ch] = acc;
+        }
+    }
+    __syncthreads();
+    dec_layer(P, ldp, p.C0, p.w1p, p.b1, p.s1, p.t1, p.N1, Qb, ldq);
+    __syncthreads();
+    dec_layer(Qb, ldq, p.N1, p.w2p, p.b2, p.s2, p.t2, p.N2, P, ldp);
+    __syncthreads();
+    // ---- last layer (N2 -> OUT <= 4): one wave per 8 rows, k over lanes, butterfly sum
+    for (int qi = 0; qi < DEC_TM / 4; ++qi) {
+        const int row = wave * (DEC_TM / 4) + qi;
+        const long long m = mb + row;
+        for (int o = 0; o < p.OUT; ++o) {
+            float s = 0.f;
+            for (int k = lane; k < p.N2; k += 64) s = fmaf(P[row * ldp + k], p.w3[(size_t)o * p.N2 + k], s);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0 && m < p.M) {
+                float v = fmaxf(__fadd_rn(s, p.b3[o]), 0.f);
+                if (p.s3) v = __fadd_rn(__fmul_rn(v, p.s3[o]), p.t3[o]);
+                p.out[m * p.ldo + o] = v;
+            }
+        }
+    }
+}
+
+extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
+                                  const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
+                                  const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                                  const float *s3, const float *t3, int OUT, float *out, int ldo, void *stream) {
+    GN_REQUIRE((xin != nullptr || (vol != nullptr && D > 0 && H > 0 && W > 0)) && M >= 0 && ldo >= OUT, "gn_implicit_decode: bad sizes");
+    GN_REQUIRE(xin == nullptr || (ldxin >= C0 && ldxin % 4 == 0), "gn_implicit_decode: pre-sampled rows need a 16-byte aligned leading dimension");
+    GN_REQUIRE(C0 % 32 == 0 && N1 % 256 == 0 && N2 % 256 == 0 && OUT >= 1 && OUT <= 4,
+               "gn_implicit_decode: unsupported layer widths [%d,%d,%d,%d] (need C0 %% 32 == 0, N1 and N2 multiples of 256, out <= 4)", C0, N1, N2, OUT);
+    GN_REQUIRE(xin != nullptr || query != nullptr || (Q > 1 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_implicit_decode: bad lattice range");
+    GN_REQUIRE((s1 == nullptr) == (t1 == nullptr) && (s2 == nullptr) == (t2 == nullptr) && (s3 == nullptr) == (t3 == nullptr),
+               "gn_implicit_decode: BN scale and shift must come together");
+    if (M == 0) return GN_OK;
+    DecodeArgs p;
+    p.vol = vol; p.D = D; p.H = H; p.W = W; p.C0 = C0; p.xin = xin; p.ldxin = ldxin; p.query = query; p.Q = Q; p.m0 = m0; p.M = M;
+    p.w1p = w1p; p.b1 = b1; p.s1 = s1; p.t1 = t1; p.N1 = N1; p.w2p = w2p; p.b2 = b2; p.s2 = s2; p.t2 = t2; p.N2 = N2;
+    p.w3 = w3; p.b3 = b3; p.s3 = s3; p.t3 = t3; p.OUT = OUT; p.out = out; p.ldo = ldo;
+    const int ldp = (C0 > N2 ? C0 : N2) + 4, ldq = N1 + 4;
+    const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq);
+    GN_REQUIRE(sh <= 160 * 1024, "gn_implicit_decode: layer widths need %zu bytes of LDS", sh);
+    GN_HIP(hipFuncSetAttribute((const void *)implicit_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_implicit_decode");
+    hipLaunchKernelGGL(implicit_decode_kernel, dim3((unsigned)gn_cdiv(M, DEC_TM)), dim3(256), sh, gn_stream(stream), p);
+    GN_LAUNCH_CHECK("gn_implicit_decode");
     return GN_OK;
 }

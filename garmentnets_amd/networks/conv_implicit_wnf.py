@@ -11,7 +11,7 @@ from torch import nn
 
 from .. import ops
 from ..batch import Batch
-from ..components.mlp import MLP
+from ..components.mlp import MLP, PackedModule, fold_batchnorm
 from ..components.unet3d import Abstract3DUNet, DoubleConv, to_channel_last
 from .pointnet2_nocs import PointNet2NOCS
 
@@ -53,25 +53,50 @@ class UNet3D(nn.Module):
         return self.abstract_3d_unet(data)
 
 
-class ImplicitWNFDecoder(nn.Module):
-    """trilinear feature sampling (border, align_corners) -> MLP -- conv_implicit_wnf.py:120-149."""
+class ImplicitWNFDecoder(PackedModule):
+    """trilinear feature sampling (border, align_corners) -> MLP -- conv_implicit_wnf.py:120-149.
 
-    ROWS_PER_CHUNK = 1 << 19
+    The MLP runs as ONE kernel (gn_implicit_decode: hidden activations stay in LDS) when it has the shipped shape
+    [C0, N1, N2, out<=4] with N1, N2 multiples of 256; otherwise gn_linear per layer.  Sampling is a separate
+    high-occupancy kernel feeding it through a chunk buffer small enough to stay in the 256 MB Infinity Cache
+    (measured on MI355X, 128^3 lattice: sample 1.96 ms + MLP 4.47 ms vs 9.55 ms for sampling inside the MLP kernel,
+    where the latency-bound gathers cannot overlap the matrix-core phases of the only two resident workgroups)."""
+
+    ROWS_PER_CHUNK = 1 << 18
+    fused = True
 
     def __init__(self, nn_channels=(128, 512, 512, 1), batch_norm=True):
         super().__init__()
         self.mlp = MLP(list(nn_channels), batch_norm=batch_norm)
+        self.nn_channels = tuple(nn_channels)
         self.out_channels = nn_channels[-1]
+
+    def _pack(self):
+        ch = self.nn_channels
+        if not (len(ch) == 4 and ch[0] % 32 == 0 and ch[1] % 256 == 0 and ch[2] % 256 == 0 and ch[3] <= 4):
+            return None
+        layers = []
+        for i, block in enumerate(self.mlp):
+            w = block[0].weight.detach().float()
+            b = block[0].bias.detach().float().contiguous()
+            sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
+            layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
+        return tuple(layers)
 
     def _decode_rows(self, vol_b, out, query=None, Q=0):
         M = out.shape[0]
+        layers = self.packed() if self.fused else None
+        buf = ops.new_rows(min(M, self.ROWS_PER_CHUNK), vol_b.shape[-1], vol_b.device)
         for m0 in range(0, M, self.ROWS_PER_CHUNK):
             m = min(self.ROWS_PER_CHUNK, M - m0)
             if query is not None:
-                s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m])
+                s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m], out=buf[:m])
             else:
-                s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m)
-            out[m0:m0 + m] = self.mlp(s)
+                s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m, out=buf[:m])
+            if layers is not None:
+                ops.implicit_decode(None, layers, M=m, out=out[m0:m0 + m], xin=s)
+            else:
+                out[m0:m0 + m] = self.mlp(s)
 
     def forward(self, features_grid, query_points):
         """features_grid (B,C,D,H,W), query_points (B,M,3) in [0,1] -> (B,M,out)"""

@@ -224,6 +224,35 @@ def trilinear_sample(vol_b, query=None, Q=0, m0=0, M=None, out=None):
     return out
 
 
+def pack_kpair(w):
+    """Linear weight W[n][k] -> Wp[k/16][n][2][8] with Wp[g][n][h][j] = W[n][16g + 8h + j]: the B-operand pack of
+    gn_implicit_decode (32 contiguous bytes per lane, 2 KB per wave per 16-deep k-group)."""
+    n, k = w.shape
+    assert k % 16 == 0
+    return w.detach().float().reshape(n, k // 16, 2, 8).permute(1, 0, 2, 3).contiguous()
+
+
+def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=None):
+    """vol_b [D][H][W][C0]; layers = ((w1p,b1,s1,t1,N1), (w2p,b2,s2,t2,N2), (w3,b3,s3,t3,OUT)) -> out [M][OUT].
+    xin: optional pre-sampled rows [M][C0] (then only the MLP runs)."""
+    (w1p, b1, s1, t1, N1), (w2p, b2, s2, t2, N2), (w3, b3, s3, t3, OUT) = layers
+    if xin is not None:
+        D = H = W = 0
+        M, C0 = xin.shape
+        ldxin = rows_view(xin)[1]
+    else:
+        D, H, W, C0 = vol_b.shape
+        ldxin = 0
+    if query is not None:
+        M = query.shape[0]
+        _chk(query, torch.float32, "query")
+    if out is None:
+        out = torch.empty((M, OUT), dtype=torch.float32, device=(xin if xin is not None else vol_b).device)
+    _lib.call("gn_implicit_decode", _p(vol_b), D, H, W, C0, _p(xin), ldxin, _p(query), int(Q), int(m0), int(M), _p(w1p), _p(b1), _p(s1), _p(t1), N1,
+              _p(w2p), _p(b2), _p(s2), _p(t2), N2, _p(w3), _p(b3), _p(s3), _p(t3), OUT, _p(out), rows_view(out)[1], _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ isosurface
 def ggm3d(vol, sigma):
     _chk(vol, torch.float32, "vol")

@@ -148,6 +148,17 @@ int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *ou
 int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const float *query, int Q, int64_t m0, int64_t M,
                         float *out, int ldo, void *stream);
 
+/* Fused implicit decoder: trilinear sampling (as gn_trilinear_sample) + the 3-layer MLP of ImplicitWNFDecoder
+ * (Linear -> ReLU -> BatchNorm1d per layer, widths [C0, N1, N2, OUT]) in one kernel -- networks/conv_implicit_wnf.py:128-149,
+ * predict.py:145-157,184-187.  Activations stay in LDS; w1p / w2p are k-pair-major packs Wp[k/2][n][2] of the Linear
+ * weights W[n][k]; w3 is [OUT][N2] row-major; (s*, t*) are the folded eval-BatchNorm scale/shift (NULL = no BN).
+ * If xin != NULL the rows xin[M][C0] (ld ldxin) are used instead of sampling (two-kernel form: gn_trilinear_sample first).
+ * Constraints: C0 % 32 == 0, N1 and N2 multiples of 256, OUT <= 4 (otherwise use gn_trilinear_sample + gn_linear). */
+int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
+                       const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
+                       const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                       const float *s3, const float *t3, int OUT, float *out, int ldo, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Isosurface.
  * ------------------------------------------------------------------------------------------------------- */

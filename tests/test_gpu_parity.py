@@ -280,6 +280,31 @@ def test_trilinear_against_grid_sample():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("out_ch,M", [(1, 1000), (3, 37), (1, 32), (3, 1)])
+def test_fused_decoder_against_torch_and_unfused(out_ch, M):
+    """gn_implicit_decode (sample + 3-layer MLP in LDS) vs F.grid_sample + the oracle MLP, and vs the per-layer path."""
+    from garmentnets_amd.networks.conv_implicit_wnf import ImplicitWNFDecoder
+    g = torch.Generator().manual_seed(out_ch * 100 + M)
+    dec = ImplicitWNFDecoder((128, 256, 256, out_ch), batch_norm=True)
+    sd = {k: S.synthetic_tensor("volume_decoder." + k, tuple(v.shape), seed=3) for k, v in dec.state_dict().items()}
+    dec.load_state_dict(sd)
+    dec = dec.to(DEV).eval()
+    vol = torch.randn(2, 128, 6, 5, 7, generator=g)
+    q = torch.rand(2, M, 3, generator=g)
+    q[:, 0] = 1.0
+    ref = P.implicit_decoder({"d." + k: v for k, v in sd.items()}, "d", vol, q)
+    out = dec(vol.to(DEV), q.to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+    dec.fused = False
+    out2 = dec(vol.to(DEV), q.to(DEV))
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+    dec.fused = True
+    lat = dec.decode_lattice(vol.to(DEV), 9)
+    gp = P.grid_points(9).reshape(1, -1, 3).repeat(2, 1, 1)
+    ref_lat = P.implicit_decoder({"d." + k: v for k, v in sd.items()}, "d", vol, gp)
+    np.testing.assert_allclose(lat.reshape(2, -1, out_ch).cpu().numpy(), ref_lat.numpy(), rtol=1e-5, atol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ isosurface
 def _gpu_mc_raw(vol, level):
     v = torch.from_numpy(np.ascontiguousarray(vol, np.float32)).to(DEV)
