@@ -56,15 +56,15 @@ class ConvTimer:
         orig = ops.conv3d_gcr
         timer = self
 
-        def timed(src0, src1, a, d, wp, cout, relu=True):
+        def timed(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
             if not timer.enabled:
-                return orig(src0, src1, a, d, wp, cout, relu)
+                return orig(src0, src1, a, d, wp, cout, relu, with_stats)
             B, D, H, W, C0 = src0.shape
             cin = C0 + (0 if src1 is None else src1.shape[-1])
             nt = 2 if cout % 64 == 0 else 1
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = orig(src0, src1, a, d, wp, cout, relu)
+            out = orig(src0, src1, a, d, wp, cout, relu, with_stats)
             e1.record()
             timer.records.append((nt, 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W + wp.numel() * 4.0, e0, e1))
             return out

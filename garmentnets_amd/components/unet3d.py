@@ -35,19 +35,21 @@ class SingleConv(PackedModule, nn.Sequential):
         self.add_module("ReLU", nn.ReLU(inplace=True))
 
     def _pack(self):
-        w = self.conv.weight.detach().float()                      # (Cout, Cin, kd, kh, kw)
-        wp = w.permute(2, 3, 4, 1, 0).reshape(27, w.shape[1], w.shape[0]).contiguous()   # [tap][Cin][Cout]
+        wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
         return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
 
-    def run(self, src0, src1=None, stats0=None, stats1=None):
-        """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> [B][D][H][W][Cout]"""
+    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True):
+        """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
+        stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them."""
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None
         if src1 is not None:
             st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
-        return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True)
+        if with_stats:
+            return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True, with_stats=True)
+        return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True), None
 
 
 class DoubleConv(nn.Sequential):
@@ -62,8 +64,9 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
-    def run(self, src0, src1=None):
-        return self.SingleConv2.run(self.SingleConv1.run(src0, src1))
+    def run(self, src0, src1=None, stats0=None, stats1=None):
+        y, st = self.SingleConv1.run(src0, src1, stats0, stats1)
+        return self.SingleConv2.run(y, None, st)
 
 
 class Encoder(nn.Module):
@@ -72,10 +75,14 @@ class Encoder(nn.Module):
         self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=True, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, x):
+    def run(self, x, stats=None):
         if self.pooling is not None:
-            x = ops.maxpool3d_2(x)
-        return self.basic_module.run(x)
+            c = x.shape[-1]
+            if c <= 256 and 256 % (c // 4) == 0:
+                x, stats = ops.maxpool3d_2(x, with_stats=True)
+            else:
+                x, stats = ops.maxpool3d_2(x), None
+        return self.basic_module.run(x, None, stats)
 
 
 class Decoder(nn.Module):
@@ -83,9 +90,9 @@ class Decoder(nn.Module):
         super().__init__()
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=False, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, encoder_features, x):
+    def run(self, encoder_features, x, stats_skip=None, stats_x=None):
         # cat((encoder_features, upsample_nearest(x)), dim=channel) is never materialised
-        return self.basic_module.run(encoder_features, x)
+        return self.basic_module.run(encoder_features, x, stats_skip, stats_x)
 
 
 class FinalConv1x1(PackedModule, nn.Conv3d):
@@ -117,19 +124,21 @@ class Abstract3DUNet(nn.Module):
         self.final_conv = FinalConv1x1(f_maps[0], out_channels, 1)
         self.final_activation = None
 
-    def run(self, x):
-        """channel-last in, channel-last out"""
+    def run(self, x, stats=None):
+        """channel-last in, channel-last out.  Every kernel that produces a tensor also emits the per-channel statistics the
+        next GroupNorm needs (conv / max-pool epilogues), so no activation is re-read for normalisation."""
         feats = []
         for enc in self.encoders:
-            x = enc.run(x)
-            feats.insert(0, x)
-        for dec, skip in zip(self.decoders, feats[1:]):
-            x = dec.run(skip, x)
+            x, stats = enc.run(x, stats)
+            feats.insert(0, (x, stats))
+        for dec, (skip, skip_stats) in zip(self.decoders, feats[1:]):
+            x, stats = dec.run(skip, x, skip_stats, stats)
         return self.final_conv.run(x)
 
     def forward(self, x):
         """x: (B, C, D, H, W) as in the reference; returns (B, C', D, H, W) (a view over channel-last storage)."""
-        return self.run(to_channel_last(x)).permute(0, 4, 1, 2, 3)
+        stats = getattr(x, "_gn_stats", None)
+        return self.run(to_channel_last(x), stats).permute(0, 4, 1, 2, 3)
 
 
 def to_channel_last(x):

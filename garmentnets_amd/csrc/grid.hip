@@ -128,3 +128,52 @@ extern "C" int gn_grid_scatter(const float *src, int lds, const int32_t *flat_id
     GN_LAUNCH_CHECK("gn_grid_scatter");
     return GN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ sparse statistics
+// GroupNorm statistics of a scattered volume from its occupied cells: the first point that claims a cell (atomicCAS on
+// the count workspace, which gn_grid_scatter leaves zeroed) contributes that cell's channel values.
+// Block = 256 threads: 64 consecutive points, thread = (channel lane, point group); register partials are flushed with
+// fp64 atomics when the sample index changes (points are sorted by sample) and at the end.
+#define GS_PTS 64
+__global__ __launch_bounds__(256) void grid_stats_kernel(const float *__restrict__ vol, const int32_t *__restrict__ flat_idx, int64_t N,
+                                                         int C, int64_t cps, int32_t *__restrict__ count, double *__restrict__ sum,
+                                                         double *__restrict__ sumsq) {
+    __shared__ int owner[GS_PTS];
+    const int64_t p0 = (int64_t)blockIdx.x * GS_PTS;
+    if (threadIdx.x < GS_PTS) {
+        const int64_t p = p0 + threadIdx.x;
+        owner[threadIdx.x] = (p < N) ? (atomicCAS(&count[flat_idx[p]], 0, 1) == 0) : 0;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0, q = 0.0;
+        int64_t bcur = -1;
+        for (int i = 0; i < GS_PTS; ++i) {
+            if (!owner[i]) continue;
+            const int64_t cell = flat_idx[p0 + i];
+            const int64_t b = cell / cps;
+            if (b != bcur) {
+                if (bcur >= 0) { atomicAdd(&sum[bcur * C + c], s); atomicAdd(&sumsq[bcur * C + c], q); }
+                s = q = 0.0;
+                bcur = b;
+            }
+            const double v = (double)vol[cell * C + c];
+            s += v;
+            q += v * v;
+        }
+        if (bcur >= 0) { atomicAdd(&sum[bcur * C + c], s); atomicAdd(&sumsq[bcur * C + c], q); }
+    }
+}
+
+extern "C" int gn_grid_stats(const float *vol, const int32_t *flat_idx, int64_t N, int C, int64_t cells_per_sample, int B,
+                             int32_t *count_ws, double *sum, double *sumsq, void *stream) {
+    GN_REQUIRE(N >= 0 && C > 0 && cells_per_sample > 0 && B >= 0, "gn_grid_stats: bad sizes");
+    hipStream_t st = gn_stream(stream);
+    GN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * (size_t)B * C, st), "gn_grid_stats");
+    GN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * (size_t)B * C, st), "gn_grid_stats");
+    if (N == 0) return GN_OK;
+    hipLaunchKernelGGL(grid_stats_kernel, dim3((unsigned)gn_cdiv(N, GS_PTS)), dim3(256), 0, st, vol, flat_idx, N, C, cells_per_sample,
+                       count_ws, sum, sumsq);
+    GN_LAUNCH_CHECK("gn_grid_stats");
+    return GN_OK;
+}

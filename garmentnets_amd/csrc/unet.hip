@@ -104,11 +104,17 @@ extern "C" int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0
 // Implicit GEMM: M = output voxels, N = Cout, K = 27 taps x Cin.
 // Block = 256 threads (4 waves) -> output tile 4(z) x 8(y) x 8(x) voxels x (NT*32) output channels;
 // wave w owns z-slice w: 64 voxels = two 32-row MFMA fragments (y 0-3 / 4-7, x 0-7), NT column fragments.
-// K loop: for each 16-channel input slice { stage the 6x10x10 halo of that slice in LDS (GroupNorm affine applied
-// on the way, zeros outside the volume, source 1 read at half resolution = nearest upsampling) ; for each of the
-// 27 taps { stage W[tap][slice][:] (16 x Cout_tile) in LDS ; 8 k-steps of 2*NT MFMAs } }.
-// LDS: halo 600 voxels x 17 words (odd stride: the 32 rows of a fragment hit distinct banks up to a 2-way
-// overlap) = 40.8 KB, weights 16 x NT*32 words <= 8 KB.
+// K loop: for each 16-channel input slice { stage the 6x10x10 halo of that slice in LDS (GroupNorm affine applied on the
+// way, zeros outside the volume, source 1 read at half resolution = nearest upsampling + concat never materialised);
+// for each of the 27 taps { 8 k-steps of 2*NT MFMAs } }.
+// k order inside a slice is PERMUTED (sum order is free): MFMA j takes channel j from lanes 0-31 and channel 8+j from lanes
+// 32-63, so a lane reads 8 CONSECUTIVE channels of its voxel (2 x ds_read_b128) and 8 consecutive k of its output channel
+// from the weight tile (packed [tap][slice][cout][16], staged as wsm[n][16+4]) -- 4x fewer LDS instructions than scalar
+// fragment loads.  Pipelining: the weight tile of tap t+1 is fetched into registers during the MFMAs of tap t and written
+// to the other half of a double-buffered LDS tile (one barrier per tap); the A fragments of tap t+1 are read during tap t.
+// LDS: halo 600 voxels x 20 words = 48 KB, weights 2 x NT*32 x 20 words <= 10 KB  -> 2 workgroups per CU.
+// Optional epilogue: per-(sample, channel) sum / sum-of-squares of the (post-ReLU) output, i.e. the GroupNorm statistics
+// of the NEXT layer, reduced in-wave, across waves through LDS, then one fp64 atomic per channel per workgroup.
 #define CV_TZ 4
 #define CV_TY 8
 #define CV_TX 8
@@ -117,7 +123,7 @@ extern "C" int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0
 #define CV_HX (CV_TX + 2)
 #define CV_HVOX (CV_HZ * CV_HY * CV_HX)
 #define CV_KS 16
-#define CV_VSTRIDE (CV_KS + 1)
+#define CV_VSTRIDE (CV_KS + 4)
 
 struct ConvArgs {
     const float *src0;
@@ -126,16 +132,20 @@ struct ConvArgs {
     const float *d;
     const float *wp;
     float *out;
+    double *osum;
+    double *osq;
     int C0, C1, B, D, H, W, Cout, relu;
     int tiles_y, tiles_x;
 };
 
+struct AFrag { float4 lo, hi; };
+
 template <int NT>
-__global__ __launch_bounds__(256) void conv3d_gcr_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
     constexpr int CT = NT * 32;
-    __shared__ float halo[CV_HVOX * CV_VSTRIDE];
-    __shared__ float wsm[CV_KS * CT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float halo[CV_HVOX * CV_VSTRIDE];
+    __shared__ __attribute__((aligned(16))) float wsm[2][CT * CV_VSTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
     const int Cin = p.C0 + p.C1;
     int tile = blockIdx.x;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
@@ -152,22 +162,24 @@ __global__ __launch_bounds__(256) void conv3d_gcr_kernel(ConvArgs p) {
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[t][u][q] = 0.f;
 
-    // per-lane A-operand base offsets inside the halo for fragment 0/1 at tap (0,0,0)
-    const int fi = lane & 31;
-    const int abase0 = ((wave * CV_HY + (fi >> 3)) * CV_HX + (fi & 7)) * CV_VSTRIDE + (lane >> 5);
-    const int abase1 = abase0 + 4 * CV_HX * CV_VSTRIDE;
-    const int bbase = (lane >> 5) * CT + (lane & 31);
+    // A-operand base (float4 units) of fragment 0 at tap (0,0,0); fragment 1 is 4 halo rows further
+    const int abase = (((wave * CV_HY + (r >> 3)) * CV_HX + (r & 7)) * CV_VSTRIDE + 8 * h) >> 2;
+    constexpr int AF1 = (4 * CV_HX * CV_VSTRIDE) >> 2;
+    const int bbase = (r * CV_VSTRIDE + 8 * h) >> 2;
+    const float4 *halo4 = reinterpret_cast<const float4 *>(halo);
 
-    constexpr int WV = (CV_KS * CT / 4 + 255) / 256;  // float4 per thread for a weight tile
-    float4 wreg[WV];
-
+    // weight tile: CT x 16 floats contiguous in global ([tap][slice][cout][16]); one float4 per thread (NT=2: 256, NT=1: 128)
+    constexpr int WV4 = CT * 4;   // float4 per tile
+    const bool wact = tid < WV4;
+    const int wn = tid >> 2, wk4 = tid & 3;
     const int nslices = Cin / CV_KS;
+    const int64_t tap_stride = (int64_t)nslices * p.Cout * CV_KS;
+
     for (int s = 0; s < nslices; ++s) {
         const int c0 = s * CV_KS;
-        __syncthreads();  // previous slice fully consumed
-        // ---- halo stage
+        // ---- halo stage (the barrier that ended the previous slice's last tap protects halo and wsm)
         {
             const bool from1 = c0 >= p.C0;
             const float *src = from1 ? p.src1 : p.src0;
@@ -192,82 +204,89 @@ __global__ __launch_bounds__(256) void conv3d_gcr_kernel(ConvArgs p) {
                     v.z = __fadd_rn(__fmul_rn(xin.z, av.z), dv.z);
                     v.w = __fadd_rn(__fmul_rn(xin.w, av.w), dv.w);
                 }
-                float *h = halo + hv * CV_VSTRIDE + c4;
-                h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
+                *reinterpret_cast<float4 *>(halo + hv * CV_VSTRIDE + c4) = v;
             }
         }
-        // ---- first weight tile of this slice
-        const float *wbase = p.wp + (int64_t)c0 * p.Cout + n0;
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            int idx = tid + i * 256;
-            if (idx < CV_KS * CT / 4) {
-                int k = idx / (CT / 4), n4 = (idx % (CT / 4)) * 4;
-                wreg[i] = *reinterpret_cast<const float4 *>(wbase + (int64_t)k * p.Cout + n4);
-            }
+        const float *wslice = p.wp + ((int64_t)s * p.Cout + n0) * CV_KS;   // tap 0 of this slice
+        float4 wreg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wact) {
+            wreg = *reinterpret_cast<const float4 *>(wslice + (int64_t)tid * 4);
+            *reinterpret_cast<float4 *>(&wsm[0][wn * CV_VSTRIDE + wk4 * 4]) = wreg;
         }
+        __syncthreads();
+        AFrag a0, a1, na0, na1;
+        a0.lo = halo4[abase]; a0.hi = halo4[abase + 1];
+        a1.lo = halo4[abase + AF1]; a1.hi = halo4[abase + AF1 + 1];
+        na0 = a0; na1 = a1;
         for (int tap = 0; tap < 27; ++tap) {
-            __syncthreads();  // weight buffer free (and halo visible on the first tap)
+            const int cur = tap & 1;
+            const bool more = tap + 1 < 27;
+            if (more && wact) wreg = *reinterpret_cast<const float4 *>(wslice + (int64_t)(tap + 1) * tap_stride + (int64_t)tid * 4);
+            AFrag bf[NT];
+            const float4 *w4 = reinterpret_cast<const float4 *>(wsm[cur]);
 #pragma unroll
-            for (int i = 0; i < WV; ++i) {
-                int idx = tid + i * 256;
-                if (idx < CV_KS * CT / 4) *reinterpret_cast<float4 *>(wsm + idx * 4) = wreg[i];
+            for (int u = 0; u < NT; ++u) { bf[u].lo = w4[bbase + u * 32 * (CV_VSTRIDE >> 2)]; bf[u].hi = w4[bbase + u * 32 * (CV_VSTRIDE >> 2) + 1]; }
+            if (more) {
+                const int t1 = tap + 1;
+                const int toff = ((((t1 / 9) * CV_HY + (t1 / 3) % 3) * CV_HX + t1 % 3) * CV_VSTRIDE) >> 2;
+                na0.lo = halo4[abase + toff]; na0.hi = halo4[abase + toff + 1];
+                na1.lo = halo4[abase + AF1 + toff]; na1.hi = halo4[abase + AF1 + toff + 1];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#define CV_STEP(X)                                                                                   \
+            _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                         \
+                acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.X, bf[u].X, acc[0][u], 0, 0, 0);  \
+                acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.X, bf[u].X, acc[1][u], 0, 0, 0);  \
+            }
+            CV_STEP(lo.x) CV_STEP(lo.y) CV_STEP(lo.z) CV_STEP(lo.w) CV_STEP(hi.x) CV_STEP(hi.y) CV_STEP(hi.z) CV_STEP(hi.w)
+#undef CV_STEP
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && wact) *reinterpret_cast<float4 *>(&wsm[cur ^ 1][wn * CV_VSTRIDE + wk4 * 4]) = wreg;
             __syncthreads();
-            if (tap + 1 < 27) {
-                const float *wn = wbase + (int64_t)(tap + 1) * Cin * p.Cout;
-#pragma unroll
-                for (int i = 0; i < WV; ++i) {
-                    int idx = tid + i * 256;
-                    if (idx < CV_KS * CT / 4) {
-                        int k = idx / (CT / 4), n4 = (idx % (CT / 4)) * 4;
-                        wreg[i] = *reinterpret_cast<const float4 *>(wn + (int64_t)k * p.Cout + n4);
-                    }
-                }
-            }
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const int toff = ((dz * CV_HY + dy) * CV_HX + dx) * CV_VSTRIDE;
-#pragma unroll
-            for (int kk = 0; kk < CV_KS / 2; ++kk) {
-                const float a0 = halo[abase0 + toff + kk * 2];
-                const float a1 = halo[abase1 + toff + kk * 2];
-                float bv[NT];
-#pragma unroll
-                for (int u = 0; u < NT; ++u) bv[u] = wsm[bbase + kk * 2 * CT + u * 32];
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[u], acc[0][u], 0, 0, 0);
-                    acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[u], acc[1][u], 0, 0, 0);
-                }
-            }
+            a0 = na0; a1 = na1;
         }
     }
-    // ---- epilogue
+    // ---- epilogue: ReLU, coalesced stores, optional statistics of the output
     const int gz = z0 + wave;
-    if (gz < p.D) {
+    float ssum[NT], ssq[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const int n = n0 + u * 32 + (lane & 31);
-                if (n >= p.Cout) continue;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
-                    if (gy < p.H && gx < p.W) {
-                        float v = acc[t][u][r];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
-                    }
+        for (int u = 0; u < NT; ++u) {
+            const int n = n0 + u * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
+                if (gz < p.D && gy < p.H && gx < p.W) {
+                    float v = acc[t][u][q];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
+                    ssum[u] += v;
+                    ssq[u] = fmaf(v, v, ssq[u]);
                 }
             }
+        }
+    if (p.osum) {
+        float *red = halo;   // [2][4 waves][CT]; every wave is past its last halo / weight read (barrier after the last tap)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
+            if (h == 0) { red[wave * CT + u * 32 + r] = s2; red[4 * CT + wave * CT + u * 32 + r] = q2; }
+        }
+        __syncthreads();
+        if (tid < CT) {
+            const double s4 = (double)red[tid] + (double)red[CT + tid] + (double)red[2 * CT + tid] + (double)red[3 * CT + tid];
+            const double q4 = (double)red[4 * CT + tid] + (double)red[5 * CT + tid] + (double)red[6 * CT + tid] + (double)red[7 * CT + tid];
+            atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s4);
+            atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
+        }
     }
 }
 
-// tuning knob (gn_set_tunable("conv_nt4", 0|1)): use the 128-wide output-channel tile for Cout % 128 == 0.
-// Measured on MI355X (profiles/r01_ab_conv_tile.txt): the 64-wide tile (96 accumulator registers, 2 waves/SIMD) runs at
-// 128 TFLOP/s, the 128-wide one (304 registers, 1 wave/SIMD, spills) at 93 TFLOP/s -> default off.
+// tuning knob kept for A/B runs (gn_set_tunable): unused tunables are ignored
 static int g_conv_nt4 = 0;
 extern "C" int gn_set_tunable(const char *name, int value) {
     if (!name) return GN_EINVAL;
@@ -277,58 +296,101 @@ extern "C" int gn_set_tunable(const char *name, int value) {
 }
 
 extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                             const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, void *stream) {
+                             const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, double *out_sum,
+                             double *out_sumsq, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr: bad sizes");
     GN_REQUIRE(C0 % CV_KS == 0 && C1 % CV_KS == 0, "gn_conv3d_gcr: channel counts must be multiples of %d (C0=%d C1=%d)", CV_KS, C0, C1);
     GN_REQUIRE(Cout % 32 == 0, "gn_conv3d_gcr: Cout=%d must be a multiple of 32", Cout);
     GN_REQUIRE(C1 == 0 || (src1 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr: upsampled source needs even dims");
+    GN_REQUIRE((out_sum == nullptr) == (out_sumsq == nullptr), "gn_conv3d_gcr: out_sum and out_sumsq must come together");
     if (B == 0) return GN_OK;
+    hipStream_t st = gn_stream(stream);
+    if (out_sum) {
+        GN_HIP(hipMemsetAsync(out_sum, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr");
+        GN_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr");
+    }
     ConvArgs p;
-    p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = wp; p.out = out;
+    p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = wp; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu;
     const int tz = (int)gn_cdiv(D, CV_TZ);
     p.tiles_y = (int)gn_cdiv(H, CV_TY);
     p.tiles_x = (int)gn_cdiv(W, CV_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
-    hipStream_t st = gn_stream(stream);
-    if (Cout % 128 == 0 && g_conv_nt4) hipLaunchKernelGGL(conv3d_gcr_kernel<4>, dim3(tiles, Cout / 128, B), dim3(256), 0, st, p);
-    else if (Cout % 64 == 0) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
+    if (Cout % 64 == 0) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
     GN_LAUNCH_CHECK("gn_conv3d_gcr");
     return GN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ maxpool 2x2x2
-__global__ __launch_bounds__(256) void maxpool3d_2_kernel(const float *__restrict__ in, int B, int D, int H, int W, int C,
-                                                          float *__restrict__ out) {
+// grid (chunks of 256 pooled voxels, B).  Thread = (voxel group, 4-channel lane): float4 loads/stores; optional
+// per-channel statistics of the pooled output (next GroupNorm) reduced through LDS, one fp64 atomic pair per channel.
+#define MP_VPB 256
+__global__ __launch_bounds__(256) void maxpool3d_2_kernel(const float *__restrict__ in, int D, int H, int W, int C,
+                                                          float *__restrict__ out, double *__restrict__ osum, double *__restrict__ osq) {
+    __shared__ float red[2][256][4];
     const int Do = D >> 1, Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)B * Do * Ho * Wo * C4;
-    if (t >= total) return;
-    const int c4 = (int)(t % C4); t /= C4;
-    const int x = (int)(t % Wo); t /= Wo;
-    const int y = (int)(t % Ho); t /= Ho;
-    const int z = (int)(t % Do);
-    const int b = (int)(t / Do);
-    float4 m = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+    const int b = blockIdx.y;
+    const int64_t Vp = (int64_t)Do * Ho * Wo;
+    const int64_t v0 = (int64_t)blockIdx.x * MP_VPB;
+    const bool strided = (256 % C4) == 0;
+    const int ngrp = strided ? 256 / C4 : 1;
+    const int c4 = strided ? threadIdx.x % C4 : 0, grp = strided ? threadIdx.x / C4 : 0;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto pool = [&](int64_t v, int cc) {
+        const int x = (int)(v % Wo), y = (int)((v / Wo) % Ho), z = (int)(v / ((int64_t)Wo * Ho));
+        float4 m = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
 #pragma unroll
-    for (int dz = 0; dz < 2; ++dz)
+        for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const float4 v = *reinterpret_cast<const float4 *>(
-                    in + ((((int64_t)b * D + 2 * z + dz) * H + 2 * y + dy) * W + 2 * x + dx) * C + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-            }
-    *reinterpret_cast<float4 *>(out + ((((int64_t)b * Do + z) * Ho + y) * Wo + x) * C + c4 * 4) = m;
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float4 t = *reinterpret_cast<const float4 *>(
+                        in + ((((int64_t)b * D + 2 * z + dz) * H + 2 * y + dy) * W + 2 * x + dx) * C + cc * 4);
+                    m.x = fmaxf(m.x, t.x); m.y = fmaxf(m.y, t.y); m.z = fmaxf(m.z, t.z); m.w = fmaxf(m.w, t.w);
+                }
+        *reinterpret_cast<float4 *>(out + ((int64_t)b * Vp + v) * C + cc * 4) = m;
+        return m;
+    };
+    if (strided) {
+        for (int64_t v = v0 + grp; v < v0 + MP_VPB && v < Vp; v += ngrp) {
+            const float4 m = pool(v, c4);
+            s4.x += m.x; s4.y += m.y; s4.z += m.z; s4.w += m.w;
+            q4.x = fmaf(m.x, m.x, q4.x); q4.y = fmaf(m.y, m.y, q4.y); q4.z = fmaf(m.z, m.z, q4.z); q4.w = fmaf(m.w, m.w, q4.w);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < (int64_t)MP_VPB * C4; i += 256) {
+            const int64_t v = v0 + i / C4;
+            if (v < Vp) pool(v, (int)(i % C4));
+        }
+    }
+    if (osum == nullptr) return;   // host guarantees `strided` when statistics are requested
+    red[0][threadIdx.x][0] = s4.x; red[0][threadIdx.x][1] = s4.y; red[0][threadIdx.x][2] = s4.z; red[0][threadIdx.x][3] = s4.w;
+    red[1][threadIdx.x][0] = q4.x; red[1][threadIdx.x][1] = q4.y; red[1][threadIdx.x][2] = q4.z; red[1][threadIdx.x][3] = q4.w;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int cc = threadIdx.x >> 2, k = threadIdx.x & 3;
+        double s = 0.0, q = 0.0;
+        for (int g = 0; g < ngrp; ++g) { s += red[0][g * C4 + cc][k]; q += red[1][g * C4 + cc][k]; }
+        atomicAdd(&osum[(int64_t)b * C + threadIdx.x], s);
+        atomicAdd(&osq[(int64_t)b * C + threadIdx.x], q);
+    }
 }
 
-extern "C" int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, void *stream) {
+extern "C" int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, double *out_sum, double *out_sumsq,
+                              void *stream) {
     GN_REQUIRE(B >= 0 && D >= 2 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "gn_maxpool3d_2: bad sizes");
-    const int64_t total = (int64_t)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
-    if (total == 0) return GN_OK;
-    hipLaunchKernelGGL(maxpool3d_2_kernel, dim3((unsigned)gn_cdiv(total, 256)), dim3(256), 0, gn_stream(stream), in, B, D, H, W, C, out);
+    GN_REQUIRE((out_sum == nullptr) == (out_sumsq == nullptr), "gn_maxpool3d_2: out_sum and out_sumsq must come together");
+    GN_REQUIRE(out_sum == nullptr || (C <= 256 && 256 % (C / 4) == 0), "gn_maxpool3d_2: statistics need C/4 to divide 256 (C=%d)", C);
+    const int64_t Vp = (int64_t)(D / 2) * (H / 2) * (W / 2);
+    if (B == 0 || Vp == 0) return GN_OK;
+    hipStream_t st = gn_stream(stream);
+    if (out_sum) {
+        GN_HIP(hipMemsetAsync(out_sum, 0, sizeof(double) * (size_t)B * C, st), "gn_maxpool3d_2");
+        GN_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double) * (size_t)B * C, st), "gn_maxpool3d_2");
+    }
+    hipLaunchKernelGGL(maxpool3d_2_kernel, dim3((unsigned)gn_cdiv(Vp, MP_VPB), B), dim3(256), 0, st, in, D, H, W, C, out, out_sum, out_sumsq);
     GN_LAUNCH_CHECK("gn_maxpool3d_2");
     return GN_OK;
 }

@@ -38,8 +38,10 @@ class VolumeFeatureAggregator(nn.Module):
                                         self.include_point_feature, self.include_confidence_feature)
         if self.local_nn is not None:
             feats = self.local_nn(feats)
-        vol = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method)      # [B][G][G][G][C]
-        return vol.permute(0, 4, 1, 2, 3)
+        vol, stats = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method, with_stats=True)   # [B][G][G][G][C]
+        out = vol.permute(0, 4, 1, 2, 3)
+        out._gn_stats = stats      # GroupNorm statistics of the (mostly empty) volume, from its occupied cells only
+        return out
 
 
 class UNet3D(nn.Module):

@@ -157,15 +157,20 @@ def grid_features(feat, nocs, sim_pos, conf, batch, lower, upper, grid_shape, in
     return out, flat
 
 
-def grid_scatter(src, flat_idx, B, grid_shape, reduce):
-    """-> channel-last volume [B][G0][G1][G2][C]"""
+def grid_scatter(src, flat_idx, B, grid_shape, reduce, with_stats=False):
+    """-> channel-last volume [B][G0][G1][G2][C] (and its per-channel statistics, from the occupied cells only)"""
     N, C = src.shape
-    cells = B * int(np.prod(grid_shape))
+    cps = int(np.prod(grid_shape))
+    cells = B * cps
     vol = torch.empty((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=src.device)
     cnt = torch.empty(cells, dtype=_i32, device=src.device)
     code = {"max": 0, "mean": 1}[reduce]
     _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _stream())
-    return vol
+    if not with_stats:
+        return vol
+    s, q = _stats_buffers(B, C, src.device, True)
+    _lib.call("gn_grid_stats", _p(vol), _p(flat_idx), N, C, cps, B, _p(cnt), _p(s), _p(q), _stream())
+    return vol, (s, q, cps)
 
 
 # ------------------------------------------------------------------------------------------------ UNet
@@ -196,19 +201,36 @@ def groupnorm_affine(st0, st1, groups, eps, gamma, beta):
     return a, d
 
 
-def conv3d_gcr(src0, src1, a, d, wp, cout, relu=True):
+def pack_conv_weight(w):
+    """nn.Conv3d weight (Cout, Cin, 3, 3, 3) -> [27 taps][Cin/16][Cout][16] (the B-operand pack of gn_conv3d_gcr)."""
+    cout, cin = w.shape[:2]
+    assert cin % 16 == 0
+    return w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2).contiguous()
+
+
+def _stats_buffers(B, C, device, want):
+    if not want:
+        return None, None
+    return (torch.empty((B, C), dtype=torch.float64, device=device), torch.empty((B, C), dtype=torch.float64, device=device))
+
+
+def conv3d_gcr(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
+    """-> out, or (out, (sum, sumsq, V)) with the statistics of the output when with_stats"""
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
-    _lib.call("gn_conv3d_gcr", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(wp), B, D, H, W, cout, 1 if relu else 0, _p(out), _stream())
-    return out
+    s, q = _stats_buffers(B, cout, src0.device, with_stats)
+    _lib.call("gn_conv3d_gcr", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(wp), B, D, H, W, cout, 1 if relu else 0, _p(out),
+              _p(s), _p(q), _stream())
+    return (out, (s, q, D * H * W)) if with_stats else out
 
 
-def maxpool3d_2(x):
+def maxpool3d_2(x, with_stats=False):
     B, D, H, W, C = x.shape
     out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
-    _lib.call("gn_maxpool3d_2", _p(x), B, D, H, W, C, _p(out), _stream())
-    return out
+    s, q = _stats_buffers(B, C, x.device, with_stats)
+    _lib.call("gn_maxpool3d_2", _p(x), B, D, H, W, C, _p(out), _p(s), _p(q), _stream())
+    return (out, (s, q, (D // 2) * (H // 2) * (W // 2))) if with_stats else out
 
 
 # ------------------------------------------------------------------------------------------------ decoder

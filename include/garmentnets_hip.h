@@ -111,6 +111,12 @@ int gn_grid_features(const float *feat, int ldf, int Cf, const float *nocs, cons
 int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
                     float *vol, int32_t *count_ws, void *stream);
 
+/* Per-(sample, channel) sum / sum of squares of a scattered volume computed from its OCCUPIED cells only (all other
+ * cells are zero): the GroupNorm statistics of the first UNet layer without reading the (mostly empty) volume.
+ * cells_per_sample = G0*G1*G2; sum/sumsq [B][C] fp64 (zeroed inside).  Must run after gn_grid_scatter on the same stream. */
+int gn_grid_stats(const float *vol, const int32_t *flat_idx, int64_t N, int C, int64_t cells_per_sample, int B,
+                  int32_t *count_ws, double *sum, double *sumsq, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * 3-D UNet (channel-last volumes [B][D][H][W][C]).
  * ------------------------------------------------------------------------------------------------------- */
@@ -130,13 +136,18 @@ int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0, int64_t V
  * components/unet3d.py:53-66,19-76.  Input = channel concatenation [src0 (C0 ch, full res), src1 (C1 ch, HALF
  * res, nearest-upsampled on the fly)] (torch.cat((skip, up(x))) of components/unet3d.py:291,330); src1 may be
  * NULL.  Zero padding is applied AFTER the affine (as nn.Conv3d pads the normalised tensor).
- * wp: weights repacked [27][Cin][Cout] (tap = (kd*3+kh)*3+kw).  LDS-tiled implicit GEMM on fp32 MFMA. */
+ * wp: weights repacked [27 taps][Cin/16 slices][Cout][16] (tap = (kd*3+kh)*3+kw, channel = slice*16 + k).
+ * out_sum / out_sumsq (both NULL or both [B][Cout] fp64, zeroed inside): per-(sample, channel) sum and sum of squares
+ * of the OUTPUT, i.e. the GroupNorm statistics of the next layer, produced by the epilogue.
+ * LDS-tiled implicit GEMM on fp32 MFMA. */
 int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                  const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, void *stream);
+                  const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, double *out_sum,
+                  double *out_sumsq, void *stream);
 
-/* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C]. */
-int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, void *stream);
-
+/* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
+ * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */
+int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, double *out_sum, double *out_sumsq,
+                   void *stream);
 /* ---------------------------------------------------------------------------------------------------------
  * Implicit decoder.
  * ------------------------------------------------------------------------------------------------------- */

@@ -30,7 +30,7 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     with pytest.raises(ValueError):
         _lib.call("gn_linear", None, 4, None, 4, None, None, None, 0, 8, 0, 4, None, 4, None)   # N == 0
     with pytest.raises(ValueError):
-        _lib.call("gn_conv3d_gcr", None, 17, None, 0, None, None, None, 1, 8, 8, 8, 32, 1, None, None)   # Cin % 16
+        _lib.call("gn_conv3d_gcr", None, 17, None, 0, None, None, None, 1, 8, 8, 8, 32, 1, None, None, None, None)   # Cin % 16
     with pytest.raises(ValueError):
         _lib.call("gn_knn_interpolate", None, 4, None, None, None, None, 1, 1, 4, 9, None, 4, None)   # k > 8
     assert "k must be" in _lib.load().gn_last_error().decode()
