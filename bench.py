@@ -84,6 +84,17 @@ class ConvTimer:
         return groups
 
 
+def measured_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs of THIS command, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py) -- only quoted when
+    the workload is the one that was profiled."""
+    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    if not (os.path.exists(path) and (args.batch, args.points, args.grid, args.reduce, args.volume_size) == (16, 6000, 128, "mean", 128)):
+        return None
+    k = json.load(open(path))["kernels"].get(kernel)
+    return None if k is None else k["hbm_bytes"]
+
+
 def cpu_baseline(args, hp, sd):
     """The oracle (a torch-CPU port of the reference path: 'port') on this host's cores, bounded sample."""
     from garmentnets_amd import synthetic as S
@@ -174,7 +185,8 @@ def main():
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": f"conv3d_gcr_kernel<{key}>", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": measured_traffic(args, f"conv3d_gcr_kernel<{key}>"),
                          "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["flops"] / g["n"],
                          "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
                          "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,

@@ -114,9 +114,17 @@ extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, 
 
 // ================================================================================================ min / max
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out_enc) {
+    __shared__ float smn[4], smx[4];
     float mn = 3.4e38f, mx = -3.4e38f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = x[i];
+    const int64_t n4 = n >> 2;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = x[(n4 << 2) + threadIdx.x];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
     }
@@ -124,8 +132,12 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
         mn = fminf(mn, __shfl_xor(mn, off));
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
-    if ((threadIdx.x & 63) == 0) {
-        // order-preserving encodings so that integer atomics implement float min / max
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        // order-preserving encodings so that integer atomics implement float min / max (one pair per workgroup)
         unsigned emn = __float_as_uint(mn), emx = __float_as_uint(mx);
         emn = (emn & 0x80000000u) ? ~emn : (emn | 0x80000000u);
         emx = (emx & 0x80000000u) ? ~emx : (emx | 0x80000000u);
@@ -147,7 +159,8 @@ extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) {
     hipStream_t st = gn_stream(stream);
     unsigned *o = reinterpret_cast<unsigned *>(out2);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, o);
-    int blocks = (int)(gn_cdiv(n, 256) < 2048 ? gn_cdiv(n, 256) : 2048);
+    GN_REQUIRE(((uintptr_t)x & 15) == 0, "gn_minmax: x must be 16-byte aligned");
+    int blocks = (int)(gn_cdiv(n, 1024) < 512 ? gn_cdiv(n, 1024) : 512);
     hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, st, x, n, o);
     hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, st, o);
     GN_LAUNCH_CHECK("gn_minmax");
