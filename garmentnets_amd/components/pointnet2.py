@@ -61,17 +61,23 @@ class PointConv(torch.nn.Module):
 class SAModule(torch.nn.Module):
     """fps -> ball query (<=64, first in index order) -> PointConv(local_nn, max) -- components/pointnet2.py:22-33."""
 
-    def __init__(self, ratio, r, nn):
+    def __init__(self, ratio, r, nn, random_start=False):
         super().__init__()
         self.ratio = ratio
         self.r = r
         self.conv = PointConv(nn)
+        # torch_cluster.fps defaults to random_start=True (the reference is therefore non-deterministic); the build pins
+        # False (first point of each example) and exposes the upstream behaviour as a flag.
+        self.random_start = random_start
 
     def forward(self, x, pos, batch):
         seg = Segments.of(batch)
         out_sizes = [ops.fps_count(n, self.ratio) for n in seg.sizes]
         cseg = Segments(out_sizes, pos.device)
-        idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total)
+        start = None
+        if self.random_start:
+            start = torch.tensor([int(torch.randint(0, max(n, 1), (1,))) for n in seg.sizes], dtype=torch.int32).to(pos.device)
+        idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total, start)
         nbr, _ = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
         edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops)
         h = self.conv.local_nn(edges)

@@ -61,7 +61,8 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
 
 template <int PPT, bool LDS_POS>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
-                                                         const int32_t *__restrict__ out_ptr, int32_t *__restrict__ out_idx) {
+                                                         const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ start_idx,
+                                                         int32_t *__restrict__ out_idx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const int s = ptr[b], n = ptr[b + 1] - s;
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restric
         dd[j] = 3.0e38f;
     }
     if (LDS_POS) __syncthreads();
-    int last = 0;
-    if (tid == 0) out_idx[o0] = s;
+    int last = start_idx ? start_idx[b] : 0;   // torch_cluster random_start: the host draws the start; default first point
+    if (last < 0 || last >= n) last = 0;
+    if (tid == 0) out_idx[o0] = s + last;
     for (int k = 1; k < m; ++k) {
         float qx, qy, qz;
         if (LDS_POS) { qx = lx[last]; qy = ly[last]; qz = lz[last]; }
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restric
     }
 }
 
-extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, int B, int max_points_per_example,
-                      int32_t *out_idx, void *stream) {
+extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
+                      int max_points_per_example, int32_t *out_idx, void *stream) {
     GN_REQUIRE(B >= 0 && max_points_per_example >= 0, "gn_fps: bad sizes");
     if (B == 0 || max_points_per_example == 0) return GN_OK;
     const int n = max_points_per_example;
@@ -135,7 +137,7 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
 #define FPS_LAUNCH(P, L)                                                                                        \
     do {                                                                                                        \
         GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
-        hipLaunchKernelGGL((fps_kernel<P, L>), dim3(B), dim3(FPS_THREADS), sh, gn_stream(stream), pos, ptr, out_ptr, out_idx); \
+        hipLaunchKernelGGL((fps_kernel<P, L>), dim3(B), dim3(FPS_THREADS), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
     } while (0)
     if (ppt <= 1) FPS_LAUNCH(1, true);
     else if (ppt <= 2) FPS_LAUNCH(2, true);

@@ -63,10 +63,11 @@ def segment_ptr(batch, B):
     return ptr
 
 
-def fps(pos, ptr, out_ptr, max_points, m_total):
+def fps(pos, ptr, out_ptr, max_points, m_total, start_idx=None):
+    """start_idx: optional int32 [B] local start point per example (None = first point)."""
     _chk(pos, torch.float32, "pos")
     idx = torch.empty(m_total, dtype=_i32, device=pos.device)
-    _lib.call("gn_fps", _p(pos), _p(ptr), _p(out_ptr), ptr.numel() - 1, int(max_points), _p(idx), _stream())
+    _lib.call("gn_fps", _p(pos), _p(ptr), _p(out_ptr), _p(start_idx), ptr.numel() - 1, int(max_points), _p(idx), _stream())
     return idx
 
 

@@ -48,10 +48,12 @@ int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *ptr, void *s
 
 /* Farthest point sampling.  replaces torch_cluster.fps -- components/pointnet2.py:26.
  * Per example b (points ptr[b]..ptr[b+1]) emits out_ptr[b+1]-out_ptr[b] indices (GLOBAL point index) starting
- * with the example's first point; dist = (dx*dx+dy*dy)+dz*dz in fp32 without FMA; ties -> lowest index.
- * One 1024-thread workgroup per example, positions + running min-distance resident in LDS. */
-int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, int B, int max_points_per_example,
-           int32_t *out_idx, void *stream);
+ * with local point start_idx[b] (start_idx == NULL: the example's first point = torch_cluster random_start=False; the
+ * upstream default random_start=True is obtained by passing host-drawn random starts);
+ * dist = (dx*dx+dy*dy)+dz*dz in fp32 without FMA; ties -> lowest index.
+ * One 1024-thread workgroup per example, positions + running min-distance resident in registers / LDS. */
+int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
+           int max_points_per_example, int32_t *out_idx, void *stream);
 
 /* Ball query.  replaces torch_cluster.radius(max_num_neighbors=K) -- components/pointnet2.py:28-29.
  * For every centre c (a point index centre_idx[c], example b): the first K points j of example b in ascending

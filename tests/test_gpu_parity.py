@@ -59,6 +59,23 @@ def test_fps_bit_exact(sizes, ratio):
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
 
 
+def test_fps_start_index():
+    """random_start plumbing: any start index gives a valid greedy max-min sequence beginning at that point."""
+    _, pos, batch = _ragged_cloud([500, 300], 21)
+    seg, cseg = Segments([500, 300], DEV), Segments([250, 150], DEV)
+    start = torch.tensor([17, 299], dtype=torch.int32, device=DEV)
+    idx = ops.fps(pos.to(DEV), seg.ptr, cseg.ptr, 500, 400, start).cpu().numpy()
+    assert idx[0] == 17 and idx[250] == 500 + 299
+    for lo, hi, off, n in ((0, 250, 0, 500), (250, 400, 500, 300)):
+        sel = idx[lo:hi] - off
+        assert len(set(sel.tolist())) == len(sel) and sel.min() >= 0 and sel.max() < n
+        p = pos[off:off + n].double()
+        d = torch.cdist(p, p[torch.from_numpy(sel.astype(np.int64))])
+        for k in (1, 5, 60):
+            dmin = d[:, :k].min(dim=1)[0]
+            assert abs(float(dmin.max()) - float(dmin[sel[k]])) < 1e-7
+
+
 def test_segment_ptr():
     batch = torch.tensor([0, 0, 2, 2, 2, 5], dtype=torch.int64)
     ptr = ops.segment_ptr(batch.to(DEV), 7).cpu().numpy()
