@@ -50,13 +50,44 @@ extern "C" int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *p
 // One 1024-thread workgroup per example.  Thread t owns points t, t+1024, ... (PPT of them) and keeps their
 // coordinates and running min-distance in registers; a SoA copy of the positions lives in LDS so that every
 // thread can fetch the newly selected point by broadcast read.  Per step: fused (min-update, local arg-max),
-// 64-lane butterfly arg-max, one LDS exchange of 16 wave partials (double-buffered by step parity -> a single
-// barrier per step).  Key = (dist, lowest index wins).
+// wave arg-max on the DPP crossbar (quad_perm / row_half_mirror / row_mirror + 4 readlanes: max of the distance, then
+// min of the index among the lanes that hold it -> ties go to the lowest index), one LDS exchange of the 16 wave
+// partials (double-buffered by step parity -> a single barrier per step), and a 16-lane DPP reduce of the partials.
 #define FPS_THREADS 1024
 #define FPS_WAVES (FPS_THREADS / 64)
 
-__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+#define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+
+// after these four steps every 16-lane row holds its own reduction in all of its lanes
+__device__ __forceinline__ float row_max_f(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_QUAD_XOR1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_QUAD_XOR2>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_ROW_HALF_MIRROR>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_ROW_MIRROR>(__float_as_int(v))));
+    return v;
+}
+__device__ __forceinline__ int row_min_i(int v) {
+    v = min(v, dpp_i<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_i<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_i<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = row_max_f(v);
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = row_min_i(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 template <int PPT, bool LDS_POS>
@@ -107,20 +138,17 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restric
                 if (d > bv) { bv = d; bi = i; }  // ascending i: ties keep the lowest index
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            float ov = __shfl_xor(bv, off);
-            int oi = __shfl_xor(bi, off);
-            argmax_merge(bv, bi, ov, oi);
-        }
+        const float wv = wave_max_f(bv);
+        const int wi = wave_min_i(bv == wv ? bi : INT_MAX);
         const int par = (k & 1) * FPS_WAVES;
-        if (lane == 0) { pv[par + wave] = bv; pi[par + wave] = bi; }
+        if (lane == 0) { pv[par + wave] = wv; pi[par + wave] = wi; }
         __syncthreads();
-        float fv = pv[par];
-        int fi = pi[par];
-#pragma unroll
-        for (int w = 1; w < FPS_WAVES; ++w) argmax_merge(fv, fi, pv[par + w], pi[par + w]);
-        last = fi;
+        // lanes 0..15 of every wave reduce the 16 partials inside one DPP row
+        float fv = pv[par + (lane & (FPS_WAVES - 1))];
+        int fi = pi[par + (lane & (FPS_WAVES - 1))];
+        const float gv = row_max_f(fv);
+        fi = row_min_i(fv == gv ? fi : INT_MAX);
+        last = __builtin_amdgcn_readfirstlane(fi);
         if (tid == 0) out_idx[o0 + k] = s + last;
     }
 }
