@@ -156,13 +156,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
     const int b = blockIdx.z;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
 
-    f32x16 acc[2][NT];
+    // two-level summation: `acc` chains the 27 x 16 products of ONE channel slice on the matrix cores, `tot` adds the
+    // slice partials on the VALU -- shortens the fp32 rounding chain from 27*Cin to 432 terms (+ Cin/16 adds)
+    f32x16 acc[2][NT], tot[2][NT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][u][q] = 0.f;
+            for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
     // A-operand base (float4 units) of fragment 0 at tap (0,0,0); fragment 1 is 4 halo rows further
     const int abase = (((wave * CV_HY + (r >> 3)) * CV_HX + (r & 7)) * CV_VSTRIDE + 8 * h) >> 2;
@@ -245,6 +247,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
             __syncthreads();
             a0 = na0; a1 = na1;
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
     }
     // ---- epilogue: ReLU, coalesced stores, optional statistics of the output
     const int gz = z0 + wave;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = acc[t][u][q];
+                    float v = tot[t][u][q];
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;

@@ -296,11 +296,11 @@ def test_unet_against_reference_module(golden_dir, name):
     y = model.unet_3d(x.to(DEV)).cpu().numpy()
     # dense N(0,1) input: outputs reach |y| ~ 5, so the 1e-4 budget is applied relative to magnitude as well; the
     # fp64 restatement shows both fp32 implementations sit within a few 1e-5 of the exact result
-    np.testing.assert_allclose(y, g["y"], rtol=2e-4, atol=TOL)
+    np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=TOL)
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in S.synthetic_state_dict(S.default_hparams(grid=G), seed).items()}
     with torch.no_grad():
         y64 = P.unet3d(sd64, S.default_hparams(grid=G)["unet3d_params"], x.double()).numpy()
-    assert np.abs(y - y64).max() <= 4 * max(np.abs(g["y"] - y64).max(), 2.5e-5)
+    assert np.abs(y - y64).max() <= 2 * max(np.abs(g["y"] - y64).max(), 2.5e-5)   # as accurate as the reference's own fp32 path
 
 
 def test_trilinear_against_grid_sample():
