@@ -13,20 +13,17 @@ __device__ __forceinline__ float src_index(float q, int size) {
     return fminf((float)(size - 1), fmaxf(x, 0.0f));
 }
 
-// one wavefront per query, channels over lanes
-__global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict__ vol, int D, int H, int W, int C,
-                                                        const float *__restrict__ query, int Q, int64_t m0, int64_t M,
-                                                        float *__restrict__ out, int ldo) {
-    const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (m >= M) return;
+// one query, channels over the lanes of one wavefront
+__device__ __forceinline__ void tri_query(const float *__restrict__ vol, int D, int H, int W, int C, const float *__restrict__ query,
+                                          int Q, int64_t m0, int64_t m, float *__restrict__ out, int ldo, int lane) {
     float qx, qy, qz;
     if (query) {
         qx = query[m * 3]; qy = query[m * 3 + 1]; qz = query[m * 3 + 2];
     } else {
         // gridding.py:139-159: grid_idx.float() * ((uc-lc)/(Q-1)) + (-lc), unit cube
-        const int64_t g = m0 + m;
-        const int k = (int)(g % Q), j = (int)((g / Q) % Q), i = (int)(g / ((int64_t)Q * Q));
+        const unsigned g = (unsigned)(m0 + m), uq = (unsigned)Q;   // Q^3 < 2^32 (checked on the host): 32-bit divides
+        const unsigned gq = g / uq;
+        const int k = (int)(g - gq * uq), i = (int)(gq / uq), j = (int)(gq - (unsigned)i * uq);
         const float sc = __fdiv_rn(1.0f, __fsub_rn((float)Q, 1.0f));
         qx = __fadd_rn(__fmul_rn((float)i, sc), -0.0f);
         qy = __fadd_rn(__fmul_rn((float)j, sc), -0.0f);
@@ -48,6 +45,23 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
         const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
         ok[c] = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
         off[c] = (((int64_t)zz * H + yy) * W + xx) * C;
+    }
+    if (lane < 0) {
+        // 16-byte mode (C % 4 == 0, C <= 128): lane = -(1 + channel quad); a query occupies C/4 lanes, so a wavefront
+        // serves 64/(C/4) queries at once with 16-byte loads and stores
+        const int ch = (-lane - 1) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (ok[c]) {
+                const float4 v = *reinterpret_cast<const float4 *>(vol + off[c] + ch);
+                acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, wgt[c]));
+                acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, wgt[c]));
+                acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, wgt[c]));
+                acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, wgt[c]));
+            }
+        *reinterpret_cast<float4 *>(out + m * ldo + ch) = acc;
+        return;
     }
     if ((C & 1) == 0) {
         // two channels per lane: one 8-byte load per corner per lane, 512 contiguous bytes per wave for C = 128
@@ -73,13 +87,32 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
     }
 }
 
+// each wavefront walks TRI_QPW consecutive queries (amortises wave launch, keeps several queries' gathers in flight)
+#define TRI_QPW 8
+__global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict__ vol, int D, int H, int W, int C,
+                                                        const float *__restrict__ query, int Q, int64_t m0, int64_t M,
+                                                        float *__restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t mb = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TRI_QPW;
+    const int lpq = C >> 2;   // lanes per query in 16-byte mode
+    if ((C & 3) == 0 && lpq <= 32 && (64 % lpq) == 0 && (ldo & 3) == 0) {
+        const int qpw = 64 / lpq, sub = lane / lpq, c4 = lane % lpq;
+        for (int q = sub; q < TRI_QPW; q += qpw)
+            if (mb + q < M) tri_query(vol, D, H, W, C, query, Q, m0, mb + q, out, ldo, -(1 + c4));
+        return;
+    }
+#pragma unroll 2
+    for (int q = 0; q < TRI_QPW; ++q)
+        if (mb + q < M) tri_query(vol, D, H, W, C, query, Q, m0, mb + q, out, ldo, lane);
+}
+
 extern "C" int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const float *query, int Q, int64_t m0, int64_t M,
                                    float *out, int ldo, void *stream) {
     GN_REQUIRE(D > 0 && H > 0 && W > 0 && C > 0 && M >= 0 && ldo >= C, "gn_trilinear_sample: bad sizes");
-    GN_REQUIRE(query != nullptr || (Q > 1 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_trilinear_sample: bad lattice range");
+    GN_REQUIRE(query != nullptr || (Q > 1 && Q <= 1024 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_trilinear_sample: bad lattice range");
     GN_REQUIRE((C & 1) || (ldo % 2 == 0), "gn_trilinear_sample: even channel counts need an even output leading dimension");
     if (M == 0) return GN_OK;
-    hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gn_cdiv(M, 4)), dim3(256), 0, gn_stream(stream), vol, D, H, W, C, query, Q, m0, M,
+    hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gn_cdiv(M, 4 * TRI_QPW)), dim3(256), 0, gn_stream(stream), vol, D, H, W, C, query, Q, m0, M,
                        out, ldo);
     GN_LAUNCH_CHECK("gn_trilinear_sample");
     return GN_OK;
@@ -128,8 +161,31 @@ __device__ __forceinline__ void dec_mfma8(const float4 &a0, const float4 &a1, co
 #undef DEC_STEP
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dec_dpp(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+// sum over the 16 lanes of a DPP row (quad xor 1, quad xor 2, row_half_mirror, row_mirror); every lane gets the sum
+__device__ __forceinline__ float dec_row_sum(float v) {
+    v += dec_dpp<0xB1>(v);
+    v += dec_dpp<0x4E>(v);
+    v += dec_dpp<0x141>(v);
+    v += dec_dpp<0x140>(v);
+    return v;
+}
+
+// OUTC == 0: write Y = bn(relu(X W^T + b)) to LDS.  OUTC > 0: this is the last hidden layer -- its activations never
+// leave the registers: each lane multiplies its columns by the OUTC rows of w3 [OUTC][N] and the partial dot products are
+// reduced over the 16-lane DPP rows into red[8 partials][32 rows][OUTC] (fixed summation order -> deterministic).
+template <int OUTC>
 __device__ __forceinline__ void dec_layer(const float *__restrict__ X, int ldx, int K, const float *__restrict__ Wp, const float *__restrict__ bias,
-                                          const float *__restrict__ sc, const float *__restrict__ sh, int N, float *__restrict__ Y, int ldy) {
+                                          const float *__restrict__ sc, const float *__restrict__ sh, int N, float *__restrict__ Y, int ldy,
+                                          const float *__restrict__ w3 = nullptr, float *__restrict__ red = nullptr) {
+    float psum[16][OUTC > 0 ? OUTC : 1];
+    if (OUTC > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int o = 0; o < (OUTC > 0 ? OUTC : 1); ++o) psum[q][o] = 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const float4 *xrow = reinterpret_cast<const float4 *>(X + r * ldx + 8 * h);   // + 4*g float4 per group
     const int ng = K >> 4;                                                          // even (K % 32 == 0)
@@ -166,23 +222,46 @@ __device__ __forceinline__ void dec_layer(const float *__restrict__ X, int ldx, 
         for (int u = 0; u < 2; ++u) {
             const int n = n0 + u * 32 + r;
             const float bv = bias[n], scv = sc ? sc[n] : 1.f, shv = sh ? sh[n] : 0.f;
+            float w3v[OUTC > 0 ? OUTC : 1];
+            if (OUTC > 0) {
+#pragma unroll
+                for (int o = 0; o < (OUTC > 0 ? OUTC : 1); ++o) w3v[o] = w3[(size_t)o * N + n];
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                 float v = __fadd_rn(u == 0 ? acc0[q] : acc1[q], bv);
                 v = fmaxf(v, 0.f);
                 if (sc) v = __fadd_rn(__fmul_rn(v, scv), shv);
-                Y[row * ldy + n] = v;
+                if (OUTC > 0) {
+#pragma unroll
+                    for (int o = 0; o < (OUTC > 0 ? OUTC : 1); ++o) psum[q][o] = fmaf(v, w3v[o], psum[q][o]);
+                } else {
+                    Y[row * ldy + n] = v;
+                }
+            }
+        }
+    }
+    if (OUTC > 0) {
+        const int part = wave * 2 + ((lane >> 4) & 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+#pragma unroll
+            for (int o = 0; o < (OUTC > 0 ? OUTC : 1); ++o) {
+                const float sum = dec_row_sum(psum[q][o]);
+                if ((lane & 15) == 0) red[(part * DEC_TM + row) * OUTC + o] = sum;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void implicit_decode_kernel(DecodeArgs p) {
+template <int OUTC>
+__global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ldp = (p.C0 > p.N2 ? p.C0 : p.N2) + 4, ldq = p.N1 + 4;
-    float *P = dsm, *Qb = dsm + DEC_TM * ldp;
+    const int ldp = p.C0 + 4, ldq = p.N1 + 4;
+    float *P = dsm, *Qb = dsm + DEC_TM * ldp, *red = Qb + DEC_TM * ldq;   // X0 | H1 | 8 x 32 x OUT partial dot products
     const long long mb = (long long)blockIdx.x * DEC_TM;
     // ---- phase 0: X0 = pre-sampled rows (coalesced 16-byte loads) or trilinear sampling of 8 queries per wave
     if (p.xin) {
@@ -202,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void implicit_decode_kernel(DecodeArgs p) {
         if (p.query) {
             qx = p.query[m * 3]; qy = p.query[m * 3 + 1]; qz = p.query[m * 3 + 2];
         } else {
-            const long long g = p.m0 + m;
-            const int k = (int)(g % p.Q), j = (int)((g / p.Q) % p.Q), i = (int)(g / ((long long)p.Q * p.Q));
+            const unsigned g = (unsigned)(p.m0 + m), uq = (unsigned)p.Q;
+            const unsigned gq = g / uq;
+            const int k = (int)(g - gq * uq), i = (int)(gq / uq), j = (int)(gq - (unsigned)i * uq);
             const float sc = __fdiv_rn(1.0f, __fsub_rn((float)p.Q, 1.0f));
             qx = __fadd_rn(__fmul_rn((float)i, sc), -0.0f);
             qy = __fadd_rn(__fmul_rn((float)j, sc), -0.0f);
@@ -230,24 +310,21 @@ __global__ __launch_bounds__(256, 2) void implicit_decode_kernel(DecodeArgs p) {
         }
     }
     __syncthreads();
-    dec_layer(P, ldp, p.C0, p.w1p, p.b1, p.s1, p.t1, p.N1, Qb, ldq);
+    dec_layer<0>(P, ldp, p.C0, p.w1p, p.b1, p.s1, p.t1, p.N1, Qb, ldq);
     __syncthreads();
-    dec_layer(Qb, ldq, p.N1, p.w2p, p.b2, p.s2, p.t2, p.N2, P, ldp);
+    // second hidden layer + the (N2 -> OUT) output layer; H2 stays in registers
+    dec_layer<OUTC>(Qb, ldq, p.N1, p.w2p, p.b2, p.s2, p.t2, p.N2, nullptr, 0, p.w3, red);
     __syncthreads();
-    // ---- last layer (N2 -> OUT <= 4): one wave per 8 rows, k over lanes, butterfly sum
-    for (int qi = 0; qi < DEC_TM / 4; ++qi) {
-        const int row = wave * (DEC_TM / 4) + qi;
+    if (threadIdx.x < DEC_TM * OUTC) {
+        const int row = threadIdx.x / OUTC, o = threadIdx.x % OUTC;
         const long long m = mb + row;
-        for (int o = 0; o < p.OUT; ++o) {
-            float s = 0.f;
-            for (int k = lane; k < p.N2; k += 64) s = fmaf(P[row * ldp + k], p.w3[(size_t)o * p.N2 + k], s);
+        float sacc = 0.f;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0 && m < p.M) {
-                float v = fmaxf(__fadd_rn(s, p.b3[o]), 0.f);
-                if (p.s3) v = __fadd_rn(__fmul_rn(v, p.s3[o]), p.t3[o]);
-                p.out[m * p.ldo + o] = v;
-            }
+        for (int j = 0; j < 8; ++j) sacc += red[(j * DEC_TM + row) * OUTC + o];
+        if (m < p.M) {
+            float v = fmaxf(__fadd_rn(sacc, p.b3[o]), 0.f);
+            if (p.s3) v = __fadd_rn(__fmul_rn(v, p.s3[o]), p.t3[o]);
+            p.out[m * p.ldo + o] = v;
         }
     }
 }
@@ -260,7 +337,7 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
     GN_REQUIRE(xin == nullptr || (ldxin >= C0 && ldxin % 4 == 0), "gn_implicit_decode: pre-sampled rows need a 16-byte aligned leading dimension");
     GN_REQUIRE(C0 % 32 == 0 && N1 % 256 == 0 && N2 % 256 == 0 && OUT >= 1 && OUT <= 4,
                "gn_implicit_decode: unsupported layer widths [%d,%d,%d,%d] (need C0 %% 32 == 0, N1 and N2 multiples of 256, out <= 4)", C0, N1, N2, OUT);
-    GN_REQUIRE(xin != nullptr || query != nullptr || (Q > 1 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_implicit_decode: bad lattice range");
+    GN_REQUIRE(xin != nullptr || query != nullptr || (Q > 1 && Q <= 1024 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_implicit_decode: bad lattice range");
     GN_REQUIRE((s1 == nullptr) == (t1 == nullptr) && (s2 == nullptr) == (t2 == nullptr) && (s3 == nullptr) == (t3 == nullptr),
                "gn_implicit_decode: BN scale and shift must come together");
     if (M == 0) return GN_OK;
@@ -268,11 +345,21 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
     p.vol = vol; p.D = D; p.H = H; p.W = W; p.C0 = C0; p.xin = xin; p.ldxin = ldxin; p.query = query; p.Q = Q; p.m0 = m0; p.M = M;
     p.w1p = w1p; p.b1 = b1; p.s1 = s1; p.t1 = t1; p.N1 = N1; p.w2p = w2p; p.b2 = b2; p.s2 = s2; p.t2 = t2; p.N2 = N2;
     p.w3 = w3; p.b3 = b3; p.s3 = s3; p.t3 = t3; p.OUT = OUT; p.out = out; p.ldo = ldo;
-    const int ldp = (C0 > N2 ? C0 : N2) + 4, ldq = N1 + 4;
-    const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq);
+    const int ldp = C0 + 4, ldq = N1 + 4;
+    const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq + 8 * OUT);
     GN_REQUIRE(sh <= 160 * 1024, "gn_implicit_decode: layer widths need %zu bytes of LDS", sh);
-    GN_HIP(hipFuncSetAttribute((const void *)implicit_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_implicit_decode");
-    hipLaunchKernelGGL(implicit_decode_kernel, dim3((unsigned)gn_cdiv(M, DEC_TM)), dim3(256), sh, gn_stream(stream), p);
+#define DEC_LAUNCH(O)                                                                                                                  \
+    do {                                                                                                                               \
+        GN_HIP(hipFuncSetAttribute((const void *)implicit_decode_kernel<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_implicit_decode"); \
+        hipLaunchKernelGGL(implicit_decode_kernel<O>, dim3((unsigned)gn_cdiv(M, DEC_TM)), dim3(256), sh, gn_stream(stream), p);        \
+    } while (0)
+    switch (OUT) {
+        case 1: DEC_LAUNCH(1); break;
+        case 2: DEC_LAUNCH(2); break;
+        case 3: DEC_LAUNCH(3); break;
+        default: DEC_LAUNCH(4); break;
+    }
+#undef DEC_LAUNCH
     GN_LAUNCH_CHECK("gn_implicit_decode");
     return GN_OK;
 }
