@@ -61,7 +61,8 @@ class ConvTimer:
                 return orig(src0, src1, a, d, wp, cout, relu, with_stats)
             B, D, H, W, C0 = src0.shape
             cin = C0 + (0 if src1 is None else src1.shape[-1])
-            nt = 2 if cout % 64 == 0 else 1
+            tiles = -(-D // 4) * -(-H // 8) * -(-W // 8)
+            nt = 2 if (cout % 64 == 0 and tiles * (cout // 64) * B >= 1024) else 1
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = orig(src0, src1, a, d, wp, cout, relu, with_stats)

@@ -324,7 +324,9 @@ extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C
     p.tiles_y = (int)gn_cdiv(H, CV_TY);
     p.tiles_x = (int)gn_cdiv(W, CV_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
-    if (Cout % 64 == 0) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
+    // small volumes / small batches: the 32-wide column tile doubles the number of workgroups (same per-CU throughput)
+    const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
+    if (wide) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
     GN_LAUNCH_CHECK("gn_conv3d_gcr");
     return GN_OK;
