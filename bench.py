@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--grid", type=int, default=128, help="feature-volume edge G (north_star: 128; reference ckpt default: 32)")
     ap.add_argument("--reduce", default="mean", choices=["mean", "max"])
     ap.add_argument("--volume-size", type=int, default=128, help="WNF query volume edge Q")
+    ap.add_argument("--conv-split", type=int, default=0, choices=[0, 2, 3],
+                    help="OPT-IN: run the 3x3x3 convs on the bf16 matrix cores with an exact 2- or 3-plane operand split "
+                         "(csrc/unet_split.hip); 0 = fp32 MFMA (default, the number this bench is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-garments", type=int, default=1)
     return ap.parse_args()
@@ -153,6 +156,24 @@ def main():
     data = Batch(sizes=[args.points] * args.batch, x=x, pos=pos, batch=batch).to(dev)   # resident in HBM before timing
     timer = ConvTimer()
     timer.install()
+    if args.conv_split:
+        from garmentnets_amd import ops as _ops
+        _ops.CONV_SPLIT_PLANES = args.conv_split
+        orig_split = _ops.conv3d_gcr_split
+
+        def timed_split(src0, src1, a, d, wps, planes, cout, relu=True, with_stats=False):
+            if not timer.enabled:
+                return orig_split(src0, src1, a, d, wps, planes, cout, relu, with_stats)
+            B, D, H, W, C0 = src0.shape
+            cin = C0 + (0 if src1 is None else src1.shape[-1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_split(src0, src1, a, d, wps, planes, cout, relu, with_stats)
+            e1.record()
+            timer.records.append((f"split{planes}", 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W, e0, e1))
+            return out
+
+        _ops.conv3d_gcr_split = timed_split
 
     def step():
         return predict_batch(model, data, volume_size=args.volume_size, iso_surface_level=0.5, gradient_sigma=0.5,
@@ -194,14 +215,14 @@ def main():
             "metric": "garments/s end-to-end predict (PointNet++ -> gridding -> UNet3D -> WNF decode -> marching cubes)",
             "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not args.conv_split else f"f32 via exact {args.conv_split}-plane bf16 operand split (opt-in)", "data": "synthetic",
             "config": {"workload": f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, "
                                    f"{args.grid}^3 feature volume ({args.reduce}), {args.volume_size}^3 WNF + GGM + MC33 + surface decode",
                        "batch_per_gpu": args.batch, "points": args.points, "grid": args.grid, "reduce": args.reduce,
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level else 0.5,
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": f"conv3d_gcr_kernel<{key}>", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": f"conv3d_gcr_kernel<{key}>" if not args.conv_split else f"conv3d_split_kernel<P={args.conv_split}> (fp32-equivalent FLOPs)", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": measured_traffic(args, f"conv3d_gcr_kernel<{key}>"),
                          "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["flops"] / g["n"],

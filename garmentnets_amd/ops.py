@@ -209,6 +209,33 @@ def pack_conv_weight(w):
     return w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2).contiguous()
 
 
+# Opt-in split-precision convolution (0 = fp32 MFMA, the default and the only mode bench.py measures unless asked;
+# 2 / 3 = bf16 planes per operand, see csrc/unet_split.hip).
+CONV_SPLIT_PLANES = 0
+
+
+def pack_conv_weight_split(w, planes):
+    """(Cout, Cin, 3,3,3) fp32 -> exact bf16 plane decomposition packed [27][Cin/16][Cout][planes][16] (int16 bit patterns)."""
+    cout, cin = w.shape[:2]
+    base = w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2)   # [27][S][Cout][16]
+    out, r = [], base
+    for _ in range(planes):
+        p = r.to(torch.bfloat16)
+        out.append(p)
+        r = r - p.float()
+    return torch.stack(out, dim=3).contiguous().view(torch.int16)          # [27][S][Cout][planes][16]
+
+
+def conv3d_gcr_split(src0, src1, a, d, wps, planes, cout, relu=True, with_stats=False):
+    B, D, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[-1]
+    out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
+    s, q = _stats_buffers(B, cout, src0.device, with_stats)
+    _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(wps), int(planes), B, D, H, W, cout, 1 if relu else 0,
+              _p(out), _p(s), _p(q), _stream())
+    return (out, (s, q, D * H * W)) if with_stats else out
+
+
 def _stats_buffers(B, C, device, want):
     if not want:
         return None, None

@@ -146,6 +146,14 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
                   const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, double *out_sum,
                   double *out_sumsq, void *stream);
 
+/* OPT-IN split-precision variant of gn_conv3d_gcr (never used unless the host asks for it): identical contract, but the
+ * fp32 operands are decomposed exactly into `planes` (2 or 3) bf16 planes and multiplied on the bf16 matrix cores with fp32
+ * accumulation (3 resp. 6 partial products; planes = 3 drops only terms <= 2^-24 relative).  wp_planes: bf16 weight pack
+ * [27 taps][Cin/16][Cout][planes][16] (garmentnets_amd.ops.pack_conv_weight_split). */
+int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
+                        const void *wp_planes, int planes, int B, int D, int H, int W, int Cout, int relu, float *out,
+                        double *out_sum, double *out_sumsq, void *stream);
+
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */
 int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, double *out_sum, double *out_sumsq,

@@ -194,6 +194,27 @@ def test_pipeline_against_reference_goldens(golden_dir, name):
     assert torch.equal(out, wnf[0])
 
 
+@pytest.mark.parametrize("planes", [3, 2])
+def test_pipeline_split_precision_mode(golden_dir, planes):
+    """opt-in split-precision convs: the whole pipeline against the reference goldens, same 1e-4 budget on the WNF"""
+    g = np.load(os.path.join(golden_dir, "ref_dress_g32.npz"))
+    B, n, G, Q, seed, stride = [int(v) for v in g["meta"]]
+    model = _model(S.default_hparams(grid=G, reduce_method=str(g["reduce_method"])), seed)
+    x, pos, batch = S.synthetic_cloud(B, n, seed)
+    data = Batch(sizes=[n] * B, x=x, pos=pos, batch=batch).to(DEV)
+    try:
+        ops.CONV_SPLIT_PLANES = planes
+        p2 = model.pointnet2_forward(data)
+        u3 = model.unet3d_forward(p2)
+        wnf = model.volume_lattice_forward(u3, Q)["pred_volume"][0].cpu().numpy()
+    finally:
+        ops.CONV_SPLIT_PLANES = 0
+    err_vol = np.abs(u3["out_feature_volume"].cpu().numpy()[:, ::16, ::3, ::3, ::3] - g["out_volume_probe"]).max()
+    err_wnf = np.abs(wnf - g["wnf_volume"]).max()
+    print(f"split planes={planes}: feature-volume err {err_vol:.2e}, WNF err {err_wnf:.2e}")
+    assert err_wnf <= TOL and err_vol <= (TOL if planes == 3 else 5 * TOL)
+
+
 def test_sa_module_graph_bit_exact():
     """fps order and ball-query tables of both set-abstraction levels, on the BASELINE cloud size."""
     hp = S.default_hparams()
@@ -272,6 +293,33 @@ def test_conv3d_gcr_against_torch(C0, C1, Cout, dims):
     np.testing.assert_allclose(osum.cpu().numpy(), rs.cpu().numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(osq.cpu().numpy(), rq.cpu().numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(osum.cpu().numpy(), ref.double().sum(dim=(2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("planes,tol", [(3, 2e-5), (2, 2e-4)])
+@pytest.mark.parametrize("C0,C1,Cout,dims", [(128, 0, 128, (8, 8, 8)), (64, 128, 64, (8, 8, 16)), (16, 0, 32, (3, 5, 9)), (32, 0, 256, (4, 8, 8))])
+def test_conv3d_split_against_torch(C0, C1, Cout, dims, planes, tol):
+    """opt-in split-precision conv (bf16 planes on the matrix cores) against torch fp32 and against the fp32-MFMA kernel"""
+    g = torch.Generator().manual_seed(C0 + C1 + Cout + planes)
+    B, (D, H, W) = 2, dims
+    x0 = torch.randn(B, C0, D, H, W, generator=g)
+    x1 = torch.randn(B, C1, D // 2, H // 2, W // 2, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3, generator=g) / (27 * (C0 + C1)) ** 0.5
+    gamma = torch.rand(C0 + C1, generator=g) + 0.5
+    beta = torch.randn(C0 + C1, generator=g)
+    xin = x0 if x1 is None else torch.cat((x0, F.interpolate(x1, size=(D, H, W), mode="nearest")), dim=1)
+    ref64 = F.relu(F.conv3d(F.group_norm(xin.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1))
+    s0 = x0.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    s1 = None if x1 is None else x1.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    a, d = ops.groupnorm_affine(ops.channel_stats(s0), None if s1 is None else ops.channel_stats(s1), 8, 1e-5, gamma.to(DEV), beta.to(DEV))
+    out32 = ops.conv3d_gcr(s0, s1, a, d, ops.pack_conv_weight(w).to(DEV), Cout).permute(0, 4, 1, 2, 3).cpu().double()
+    wps = ops.pack_conv_weight_split(w, planes).to(DEV)
+    out, (osum, osq, V) = ops.conv3d_gcr_split(s0, s1, a, d, wps, planes, Cout, with_stats=True)
+    got = out.permute(0, 4, 1, 2, 3).cpu().double()
+    e_split, e_f32 = (got - ref64).abs().max().item(), (out32 - ref64).abs().max().item()
+    assert e_split <= tol, (e_split, e_f32)
+    if planes == 3:
+        assert e_split <= 2 * max(e_f32, 2e-6), (e_split, e_f32)      # as accurate as the fp32 matrix-core kernel
+    np.testing.assert_allclose(osum.cpu().numpy(), got.sum(dim=(2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("C,dims", [(16, (6, 8, 10)), (32, (8, 8, 8)), (128, (4, 6, 2)), (20, (4, 4, 4))])
