@@ -67,7 +67,14 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
                 res.update(nan_placeholder(vol.device))
             sl = slice(int(ptr[b]), int(ptr[b + 1]))
             res.update(pred_nocs=nocs_data.pos[sl], pred_nocs_confidence=nocs_data.pred_confidence[sl],
-                       pred_nocs_logits=pointnet2_result["per_point_logits"][sl])
+                       pred_nocs_logits=pointnet2_result["per_point_logits"][sl], input_points=batch.pos[sl], input_rgb=batch.x[sl])
+            # grip-point post-processing, predict.py:254-274 (tiny per-garment reductions: plain torch on device tensors)
+            bins = model.pointnet2_nocs.nocs_bins
+            glog = pointnet2_result["global_logits"][b].reshape(bins, 3)
+            res.update(pred_global_nocs_grip_point=torch.argmax(glog, dim=0).to(torch.float32) * (1.0 / (bins - 1)),
+                       pred_global_confidence=torch.softmax(glog, dim=0),
+                       pred_nocs_grip_point=nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
+                       global_feature=pointnet2_result["global_feature"][b])
             results.append(res)
         return results
 
@@ -86,6 +93,15 @@ def to_host(res):
     return out
 
 
+def to_host_groups(res):
+    """(marching_cubes_mesh, point_cloud, misc) numpy dicts = the three zarr groups predict.py:211-279 writes per sample."""
+    pc = {"pred_nocs": to_numpy(res["pred_nocs"]), "pred_nocs_confidence": to_numpy(res["pred_nocs_confidence"]),
+          "pred_nocs_logits": to_numpy(res["pred_nocs_logits"]), "input_points": to_numpy(res["input_points"]),
+          "input_rgb": to_numpy((res["input_rgb"] * 255).to(torch.uint8))}
+    misc = {k: to_numpy(res[k]) for k in ("pred_nocs_grip_point", "pred_global_nocs_grip_point", "pred_global_confidence", "global_feature")}
+    return to_host(res), pc, misc
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="GarmentNets predict (MI355X-native), synthetic-input mode")
     ap.add_argument("--checkpoint_path", default=None, help="Lightning-style .ckpt; default: seeded synthetic weights")
@@ -100,6 +116,7 @@ def main(argv=None):
     ap.add_argument("--grid", type=int, default=32)
     ap.add_argument("--reduce_method", default="max")
     ap.add_argument("--out", default=None, help="optional .npz with the last mesh")
+    ap.add_argument("--zarr_out", default=None, help="optional prediction.zarr directory (reference group layout, Zarr v2)")
     a = ap.parse_args(argv)
     device = torch.device("cuda:{}".format(a.gpu_id))
     if a.checkpoint_path:
@@ -116,6 +133,12 @@ def main(argv=None):
         res = predict_batch(model, Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch).to(device), a.volume_size,
                             a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction)[0]
         last = to_host(res)
+        if a.zarr_out:
+            from .io import zarr_store
+            root = zarr_store.open_group(a.zarr_out)
+            root.put_attrs({"subset": "synthetic"})
+            mesh, pc, misc = to_host_groups(res)
+            zarr_store.write_sample(root.require_group("samples"), f"synthetic_{i:05d}", mesh, pc, misc, attrs={"batch_idx": i})
         torch.cuda.synchronize()
         print(json.dumps({"sample": i, "verts": int(last["verts"].shape[0]), "faces": int(last["faces"].shape[0]),
                           "seconds": round(time.time() - t0, 4)}))

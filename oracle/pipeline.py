@@ -282,6 +282,18 @@ def isosurface(wnf, level, sigma, gradient_direction="ascent"):
     return dict(verts=v, faces=f, normals=n, values=a, verts_ggm=O.gather_nn(g, v, spacing), ggm=g)
 
 
+def grip_postprocess(p2, pos, batch, b, nocs_bins):
+    """predict.py:254-274 for garment b"""
+    lg = p2["global_logits"][b:b + 1]
+    bins = lg.reshape(1, nocs_bins, 3)
+    idx = torch.argmax(bins, dim=1)
+    scales = (torch.tensor([1.0] * 3) - torch.tensor([0.0] * 3)) / (torch.tensor([float(nocs_bins)] * 3) - 1)
+    sel = batch == b
+    dist = torch.norm(pos[sel], p=None, dim=1)
+    return dict(pred_global_nocs_grip_point=(idx * scales + torch.tensor([0.0] * 3))[0], pred_global_confidence=torch.softmax(bins, dim=1)[0],
+                pred_nocs_grip_point=p2["nocs_data"]["pos"][sel][torch.argmin(dist)], global_feature=p2["global_feature"][b])
+
+
 def predict(sd, hp, x, pos, batch, Q=128, level=0.5, sigma=0.5, auto_level=False):
     """predict.py:138-209 for a batch; returns per-garment results (the reference asserts batch_size==1)."""
     with torch.no_grad():
@@ -294,6 +306,7 @@ def predict(sd, hp, x, pos, batch, Q=128, level=0.5, sigma=0.5, auto_level=False
             wnf = decode_volume(sd, vol[b:b + 1], Q).numpy()
             lv = 0.5 * (float(wnf.min()) + float(wnf.max())) if auto_level else level
             r = dict(wnf_volume=wnf, level=lv)
+            r.update({k: v.numpy() for k, v in grip_postprocess(p2, pos, batch, b, hp["pointnet2_params"]["nocs_bins"]).items()})
             try:
                 iso = isosurface(wnf, lv, sigma)
                 sq = torch.from_numpy(iso["verts"].astype(np.float32)).view(1, -1, 3)

@@ -498,6 +498,11 @@ def test_predict_end_to_end_against_oracle():
                         gradient_sigma=0.5)[0]
     wnf = out["wnf_volume"].cpu().numpy()
     np.testing.assert_allclose(wnf, ref["wnf_volume"], rtol=0, atol=TOL)
+    # grip-point post-processing (predict.py:254-274)
+    assert np.array_equal(out["pred_global_nocs_grip_point"].cpu().numpy(), ref["pred_global_nocs_grip_point"])
+    assert np.array_equal(out["pred_nocs_grip_point"].cpu().numpy(), ref["pred_nocs_grip_point"])
+    np.testing.assert_allclose(out["pred_global_confidence"].cpu().numpy(), ref["pred_global_confidence"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["global_feature"].cpu().numpy(), ref["global_feature"], rtol=0, atol=TOL)
     # the isosurface of the GPU volume is bit-exact w.r.t. the oracle run on that same volume
     iso = P.isosurface(wnf, 0.5, 0.5)
     assert np.array_equal(out["faces"].cpu().numpy(), iso["faces"])

@@ -102,3 +102,52 @@ def test_batch_and_fps_count():
     assert Batch(sizes=[4, 4], batch=torch.zeros(8, dtype=torch.int64)).num_graphs == 2
     assert ops.fps_count(6000, 0.5) == 3000 and ops.fps_count(3000, 0.25) == 750 and ops.fps_count(7, 0.5) == 4
     assert ops.fps_count(1, 0.25) == 1
+
+
+def test_zarr_store_roundtrip_and_spec(tmp_path):
+    """prediction.zarr contract (predict.py:211-279): group layout, one chunk per array, Zarr v2 metadata."""
+    import json
+    from garmentnets_amd.io import zarr_store
+    rng = np.random.default_rng(0)
+    mesh = {"verts": rng.random((7, 3), dtype=np.float32), "faces": rng.integers(0, 7, (5, 3)).astype(np.int32),
+            "normals": rng.random((7, 3), dtype=np.float32), "volume_value": rng.random(7, dtype=np.float32),
+            "volume_gradient_magnitude": rng.random(7, dtype=np.float32), "warp_field": rng.random((7, 3), dtype=np.float32),
+            "is_on_surface": rng.random(7) > 0.5}
+    pc = {"pred_nocs": rng.random((9, 3), dtype=np.float32), "input_rgb": rng.integers(0, 255, (9, 3)).astype(np.uint8)}
+    misc = {"pred_nocs_grip_point": rng.random(3, dtype=np.float32), "pred_global_confidence": rng.random((64, 3), dtype=np.float32)}
+    root = zarr_store.open_group(str(tmp_path / "prediction.zarr"))
+    root.put_attrs({"subset": "test"})
+    for comp in (None, ("zlib", 6)):
+        zarr_store.write_sample(root.require_group("samples"), "k%s" % (0 if comp is None else 1), mesh, pc, misc, attrs={"batch_idx": 3}, compressor=comp)
+    back = zarr_store.open_group(str(tmp_path / "prediction.zarr"))
+    assert back.attrs == {"subset": "test"} and back["samples"].keys() == ["k0", "k1"]
+    for key in ("k0", "k1"):
+        g = back["samples"][key]
+        assert g.attrs == {"batch_idx": 3} and g.keys() == ["marching_cubes_mesh", "misc", "point_cloud"]
+        for name, ref in (("marching_cubes_mesh", mesh), ("point_cloud", pc), ("misc", misc)):
+            for k, v in ref.items():
+                got = g[name][k]
+                assert got.dtype == v.dtype and np.array_equal(got, v)
+    meta = json.load(open(tmp_path / "prediction.zarr" / "samples" / "k1" / "marching_cubes_mesh" / "verts" / ".zarray"))
+    assert meta == {"chunks": [7, 3], "compressor": {"id": "zlib", "level": 6}, "dtype": "<f4", "fill_value": 0.0, "filters": None,
+                    "order": "C", "shape": [7, 3], "zarr_format": 2}
+    assert json.load(open(tmp_path / "prediction.zarr" / "samples" / ".zgroup")) == {"zarr_format": 2}
+    assert (tmp_path / "prediction.zarr" / "samples" / "k0" / "marching_cubes_mesh" / "verts" / "0.0").exists()
+
+
+def test_delete_invalid_verts_matches_reference_semantics():
+    """common/marching_cubes_util.py:38-52 restated in numpy vs the torch version used on device tensors."""
+    from garmentnets_amd.common.marching_cubes_util import delete_invalid_verts
+    rng = np.random.default_rng(1)
+    verts = rng.random((50, 3)).astype(np.float32)
+    faces = rng.integers(0, 50, (80, 3)).astype(np.int32)
+    ok = rng.random(50) > 0.3
+    face_ok = np.ones(len(faces), dtype=bool)
+    for i in range(3):
+        face_ok &= ok[faces[:, i]]
+    raw = faces[face_ok]
+    used = np.unique(raw.flatten())
+    remap = np.zeros(50, dtype=faces.dtype)
+    remap[used] = np.arange(len(used))
+    v, f = delete_invalid_verts(torch.from_numpy(verts), torch.from_numpy(faces), torch.from_numpy(ok))
+    assert np.array_equal(v.numpy(), verts[used]) and np.array_equal(f.numpy(), remap[raw])
