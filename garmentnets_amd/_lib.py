@@ -18,7 +18,6 @@ _vp, _i32, _i64, _f32, _f64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int6
 PROTOTYPES = {
     "gn_version": [],
     "gn_device_info": [_vp, _vp],
-    "gn_set_tunable": [ctypes.c_char_p, _i32],
     "gn_segment_ptr": [_vp, _i64, _i32, _vp, _vp],
     "gn_fps": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "gn_ball_query": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp],

@@ -6,7 +6,6 @@
 // Reference: /root/reference/components/unet3d.py:19-144 (create_conv / SingleConv / DoubleConv 'gcr'),
 // :195-330 (Encoder / Decoder / Upsampling), :449-474 (forward).
 #include "common.h"
-#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -292,15 +291,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
             atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
         }
     }
-}
-
-// tuning knob kept for A/B runs (gn_set_tunable): unused tunables are ignored
-static int g_conv_nt4 = 0;
-extern "C" int gn_set_tunable(const char *name, int value) {
-    if (!name) return GN_EINVAL;
-    if (!strcmp(name, "conv_nt4")) { g_conv_nt4 = value; return GN_OK; }
-    gn_set_error("gn_set_tunable: unknown tunable %s", name);
-    return GN_EINVAL;
 }
 
 extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,

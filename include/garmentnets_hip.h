@@ -35,8 +35,6 @@ const char *gn_last_error(void);
 int gn_version(void);
 /* number of CUs / XCDs the library sees on the current device (sanity: 256 / 8 on MI355X) */
 int gn_device_info(int *num_cu, int *lds_bytes_per_cu);
-/* performance tunables (never change results): "conv_nt4" = 0|1 */
-int gn_set_tunable(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Point-set operators (PointNet++).

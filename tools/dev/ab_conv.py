@@ -1,6 +1,6 @@
 import sys, os, torch, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from garmentnets_amd import ops, _lib
+from garmentnets_amd import ops
 dev='cuda'
 def run(B,G,C0,Cout,reps=3):
     x = torch.randn(B,G,G,G,C0, device=dev)
