@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
 extern "C" int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const float *query, int Q, int64_t m0, int64_t M,
                                    float *out, int ldo, void *stream) {
     GN_REQUIRE(D > 0 && H > 0 && W > 0 && C > 0 && M >= 0 && ldo >= C, "gn_trilinear_sample: bad sizes");
+    if (M == 0) return GN_OK;   // (an empty query tensor has a NULL data pointer: not a lattice request)
     GN_REQUIRE(query != nullptr || (Q > 1 && Q <= 1024 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q), "gn_trilinear_sample: bad lattice range");
     GN_REQUIRE((C & 1) || (ldo % 2 == 0), "gn_trilinear_sample: even channel counts need an even output leading dimension");
     if (M == 0) return GN_OK;
@@ -334,6 +335,7 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
                                   const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
                                   const float *s3, const float *t3, int OUT, float *out, int ldo, void *stream) {
     GN_REQUIRE((xin != nullptr || (vol != nullptr && D > 0 && H > 0 && W > 0)) && M >= 0 && ldo >= OUT, "gn_implicit_decode: bad sizes");
+    if (M == 0) return GN_OK;
     GN_REQUIRE(xin == nullptr || (ldxin >= C0 && ldxin % 4 == 0), "gn_implicit_decode: pre-sampled rows need a 16-byte aligned leading dimension");
     GN_REQUIRE(C0 % 32 == 0 && N1 % 256 == 0 && N2 % 256 == 0 && OUT >= 1 && OUT <= 4,
                "gn_implicit_decode: unsupported layer widths [%d,%d,%d,%d] (need C0 %% 32 == 0, N1 and N2 multiples of 256, out <= 4)", C0, N1, N2, OUT);

@@ -215,6 +215,40 @@ def test_pipeline_split_precision_mode(golden_dir, planes):
     assert err_wnf <= TOL and err_vol <= (TOL if planes == 3 else 5 * TOL)
 
 
+def test_pipeline_ragged_batch_against_oracle():
+    """garments of different sizes in one batch (sorted batch vector, no host-side sizes given): every stage vs the oracle"""
+    hp = S.default_hparams(grid=16, reduce_method="mean")
+    sd = S.synthetic_state_dict(hp, 7)
+    sizes = [2500, 700, 1300]
+    x, pos, batch = _ragged_cloud(sizes, 31)
+    with torch.no_grad():
+        ref = P.pointnet2_forward(sd, hp, x, pos, batch)
+        rvol = P.unet3d(sd, hp["unet3d_params"], P.volume_agg(sd, hp["volume_agg_params"], ref["nocs_data"], 3))
+    model = _model(hp, 7)
+    p2 = model.pointnet2_forward(Batch(x=x, pos=pos, batch=batch).to(DEV))          # sizes derived from the batch vector
+    assert p2["nocs_data"].sizes == sizes
+    bins, _, _ = ops.nocs_head(p2["per_point_logits"], 64)
+    assert np.array_equal(bins.cpu().numpy(), ref["nocs_data"]["nocs_bin_idx"].numpy())
+    np.testing.assert_allclose(p2["per_point_features"].cpu().numpy(), ref["per_point_features"].numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(p2["global_feature"].cpu().numpy(), ref["global_feature"].numpy(), rtol=0, atol=TOL)
+    vol = model.unet3d_forward(p2)["out_feature_volume"]
+    np.testing.assert_allclose(vol.cpu().numpy(), rvol.numpy(), rtol=0, atol=TOL)
+
+
+def test_degenerate_sizes():
+    """zero-row launches are no-ops; k-NN with fewer sources than k uses what exists (as the oracle does)"""
+    z = ops.linear(torch.zeros(0, 8, device=DEV), torch.zeros(4, 8, device=DEV))
+    assert z.shape == (0, 4)
+    assert ops.trilinear_sample(torch.zeros(2, 2, 2, 4, device=DEV), query=torch.zeros(0, 3, device=DEV)).shape == (0, 4)
+    ps = torch.tensor([[0.0, 0, 0], [1.0, 0, 0]])
+    xs = torch.tensor([[1.0, 2.0], [3.0, 5.0]])
+    pq = torch.tensor([[0.25, 0, 0], [0.9, 0.1, 0], [0.0, 0.0, 0.0]])
+    ref = O.knn_interpolate(xs.numpy(), ps.numpy(), np.array([0, 2]), pq.numpy(), np.array([0, 3]), 3)
+    out = ops.knn_interpolate(xs.to(DEV), ps.to(DEV), Segments([2], DEV).ptr, pq.to(DEV), Segments([3], DEV).ptr, 3)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert np.allclose(out[2].cpu().numpy(), [1.0, 2.0], atol=1e-5)       # coincident point: weight 1/1e-16 dominates
+
+
 def test_sa_module_graph_bit_exact():
     """fps order and ball-query tables of both set-abstraction levels, on the BASELINE cloud size."""
     hp = S.default_hparams()
