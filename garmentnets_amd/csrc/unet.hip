@@ -146,13 +146,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float wsm[2][CT * CV_VSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
     const int Cin = p.C0 + p.C1;
-    int tile = blockIdx.x;
+    // XCD-aware work-item order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks a CONTIGUOUS
+    // range of (tile, column block) pairs, column blocks of one tile adjacent, tiles in z-fastest order -> the halo overlap of
+    // neighbouring tiles and the second column block's re-read of the same input hit that XCD's L2.  Bijective for any size.
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
+    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
+    const int ncb = p.Cout / CT;
+    int tile = (int)(logical / (unsigned)ncb);
+    const int cb = (int)(logical % (unsigned)ncb);
+    // z-fastest tile order: the z halo is the fattest (2 of 6 slices), so tiles adjacent in z run back to back
+    const int tiles_z = (p.D + 3) / 4;
+    const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y; tile /= p.tiles_y;
-    const int tz = tile;
+    const int ty = tile;
     const int z0 = tz * CV_TZ, y0 = ty * CV_TY, x0 = tx * CV_TX;
-    const int n0 = blockIdx.y * CT;
-    const int b = blockIdx.z;
+    const int n0 = cb * CT;
+    const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
 
     // two-level summation: `acc` chains the 27 x 16 products of ONE channel slice on the matrix cores, `tot` adds the
@@ -316,8 +325,8 @@ extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C
     const int tiles = tz * p.tiles_y * p.tiles_x;
     // small volumes / small batches: the 32-wide column tile doubles the number of workgroups (same per-CU throughput)
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
-    if (wide) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
+    if (wide) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
     GN_LAUNCH_CHECK("gn_conv3d_gcr");
     return GN_OK;
 }

@@ -64,13 +64,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char wsm[2][CT * VB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
     const int Cin = p.C0 + p.C1;
-    int tile = blockIdx.x;
+    // XCD-aware work-item order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks a CONTIGUOUS
+    // range of (tile, column block) pairs, column blocks of one tile adjacent, tiles in z-fastest order -> the halo overlap of
+    // neighbouring tiles and the second column block's re-read of the same input hit that XCD's L2.  Bijective for any size.
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
+    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
+    const int ncb = p.Cout / CT;
+    int tile = (int)(logical / (unsigned)ncb);
+    const int cb = (int)(logical % (unsigned)ncb);
+    // z-fastest tile order: the z halo is the fattest (2 of 6 slices), so tiles adjacent in z run back to back
+    const int tiles_z = (p.D + 3) / 4;
+    const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-    const int ty = tile % p.tiles_y; tile /= p.tiles_y;
-    const int tz = tile;
+    const int ty = tile;
     const int z0 = tz * SP_TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
-    const int n0 = blockIdx.y * CT;
-    const int b = blockIdx.z;
+    const int n0 = cb * CT;
+    const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
 
     f32x16s acc[2][NT], tot[2][NT];
@@ -262,11 +271,11 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     const int tiles = tz * p.tiles_y * p.tiles_x;
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
     if (planes == 3) {
-        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 3>), dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_kernel<1, 3>), dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
+        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 3>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_kernel<1, 3>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
     } else {
-        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 2>), dim3(tiles, Cout / 64, B), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_kernel<1, 2>), dim3(tiles, Cout / 32, B), dim3(256), 0, st, p);
+        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 2>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_kernel<1, 2>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
     }
     GN_LAUNCH_CHECK("gn_conv3d_gcr_split");
     return GN_OK;

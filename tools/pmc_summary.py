@@ -2,8 +2,9 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs (separate passes) into per-kernel HBM traffic.
 
 usage: tools/pmc_summary.py <dir_with_FETCH_SIZE_csv> <dir_with_WRITE_SIZE_csv> <steps_in_run> > profiles/rNN_conv_traffic.json
-gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly 1/2 of the bytes of coalesced streaming reads ->
-doubled; calibrated here on channel_stats_kernel, whose traffic is known exactly (reads every element once)."""
+gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced streaming reads;
+other access patterns must be calibrated on a known byte count: profiles/r01_fetch_calibration.txt (channel_stats / maxpool:
+x2.00; conv halo reads = 64-byte pieces at a channel stride: x1.26 for 128-channel inputs, x1.70 for 32-channel inputs)."""
 import collections
 import csv
 import json
@@ -19,14 +20,18 @@ def load(path):
     return agg
 
 
+FETCH_FACTOR = {"conv3d_gcr_kernel<2>": 1.26, "conv3d_gcr_kernel<1>": 1.42}   # default 2.0
+
+
 fetch = load(sys.argv[1] + "/pmc_counter_collection.csv")
 write = load(sys.argv[2] + "/pmc_counter_collection.csv")
-out = {"units": "bytes per launch (average over the run)", "fetch_correction": 2.0, "kernels": {}}
+out = {"units": "bytes per launch (average over the run)", "fetch_correction": "2.0 unless listed per kernel (calibrated)", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     if fetch[k][1] < 1024:
         continue
     n = fetch[k][0]
-    f = 2.0 * fetch[k][1] * 1024 / n
+    fac = FETCH_FACTOR.get(k, 2.0)
+    f = fac * fetch[k][1] * 1024 / n
     w = write.get(k, [n, 0.0])[1] * 1024 / n
-    out["kernels"][k] = {"launches": n, "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
+    out["kernels"][k] = {"launches": n, "fetch_factor": fac, "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
 json.dump(out, sys.stdout, indent=1)
