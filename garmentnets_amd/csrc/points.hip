@@ -455,3 +455,37 @@ extern "C" int gn_nocs_head(const float *logits, int ldl, int64_t N, int bins, i
     GN_LAUNCH_CHECK("gn_nocs_head");
     return GN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ nearest neighbour
+// Brute-force 1-NN (the cKDTree queries of the Chamfer metrics, /root/reference/eval.py:259-263,381-385).
+// Thread = one query; the reference set streams through LDS in tiles of 1024 points (SoA, broadcast reads).
+// d2 = (dx*dx+dy*dy)+dz*dz in fp32, ties -> lowest index.
+#define NN_TILE 1024
+__global__ __launch_bounds__(256) void nearest_neighbor_kernel(const float *__restrict__ q, int64_t nq, const float *__restrict__ ref,
+                                                               int64_t nr, int32_t *__restrict__ idx, float *__restrict__ d2) {
+    __shared__ float sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (i < nq) { qx = q[3 * i]; qy = q[3 * i + 1]; qz = q[3 * i + 2]; }
+    float best = 3.4e38f;
+    int bi = -1;
+    for (int64_t t0 = 0; t0 < nr; t0 += NN_TILE) {
+        const int n = (int)((nr - t0) < NN_TILE ? (nr - t0) : NN_TILE);
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) { sx[j] = ref[3 * (t0 + j)]; sy[j] = ref[3 * (t0 + j) + 1]; sz[j] = ref[3 * (t0 + j) + 2]; }
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float d = gn_sqdist3(sx[j], sy[j], sz[j], qx, qy, qz);
+            if (d < best) { best = d; bi = (int)(t0 + j); }
+        }
+    }
+    if (i < nq) { idx[i] = bi; d2[i] = best; }
+}
+
+extern "C" int gn_nearest_neighbor(const float *query, int64_t nq, const float *ref, int64_t nr, int32_t *idx, float *d2, void *stream) {
+    GN_REQUIRE(nq >= 0 && nr > 0 && nr < INT32_MAX, "gn_nearest_neighbor: bad sizes (the reference set must not be empty)");
+    if (nq == 0) return GN_OK;
+    hipLaunchKernelGGL(nearest_neighbor_kernel, dim3((unsigned)gn_cdiv(nq, 256)), dim3(256), 0, gn_stream(stream), query, nq, ref, nr, idx, d2);
+    GN_LAUNCH_CHECK("gn_nearest_neighbor");
+    return GN_OK;
+}

@@ -347,3 +347,15 @@ def scale_verts(verts_vox, spacing):
     out = torch.empty_like(verts_vox)
     _lib.call("gn_scale_verts", _p(verts_vox), verts_vox.shape[0], float(spacing), _p(out), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ evaluation helpers
+def nearest_neighbor(query, ref):
+    """-> (idx int32 [Nq], d2 float32 [Nq]) exact 1-NN of every query point in `ref`"""
+    query = _chk(query.float().contiguous(), torch.float32, "query")
+    ref = _chk(ref.float().contiguous(), torch.float32, "ref")
+    nq = query.shape[0]
+    idx = torch.empty(nq, dtype=_i32, device=query.device)
+    d2 = torch.empty(nq, dtype=torch.float32, device=query.device)
+    _lib.call("gn_nearest_neighbor", _p(query), nq, _p(ref), ref.shape[0], _p(idx), _p(d2), _stream())
+    return idx, d2

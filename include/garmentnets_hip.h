@@ -208,6 +208,15 @@ int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vo
  * surface decoder (mc_verts.astype(np.float32)). */
 int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *verts_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Widening: evaluation helpers.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Exact 1-nearest-neighbour of every query in `ref` (brute force, fp32 squared distance, ties -> lowest index).
+ * replaces the scipy cKDTree.query(k=1) calls of the Chamfer metrics -- eval.py:259-263,381-385.
+ * idx [nq] int32, d2 [nq] squared distance. */
+int gn_nearest_neighbor(const float *query, int64_t nq, const float *ref, int64_t nr, int32_t *idx, float *d2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -550,3 +550,26 @@ def test_predict_end_to_end_against_oracle():
     vol_t = model.unet3d_forward(model.pointnet2_forward(Batch(sizes=[6000], x=x, pos=pos, batch=batch).to(DEV)))
     warp_ref = P.implicit_decoder(sd, "surface_decoder", vol_t["out_feature_volume"].cpu().contiguous(), sq).view(-1, 3)
     np.testing.assert_allclose(out["warp_field"].cpu().numpy(), warp_ref.numpy(), rtol=0, atol=TOL)
+
+
+# ------------------------------------------------------------------------------------------------ widening: metrics
+def test_chamfer_against_ckdtree():
+    """eval.py:259-271,381-402 with scipy's cKDTree (the reference's own dependency) as the oracle"""
+    from scipy.spatial import cKDTree
+    from garmentnets_amd.common import metrics
+    rng = np.random.default_rng(5)
+    pred = rng.random((3001, 3)).astype(np.float32)
+    gt = (rng.random((2500, 3)) * 1.1).astype(np.float32)
+    pred_sim, gt_sim = rng.normal(size=(3001, 3)).astype(np.float32), rng.normal(size=(2500, 3)).astype(np.float32)
+    fd, fi = cKDTree(gt).query(pred, k=1)
+    bd, bi = cKDTree(pred).query(gt, k=1)
+    idx, d2 = ops.nearest_neighbor(torch.from_numpy(pred).to(DEV), torch.from_numpy(gt).to(DEV))
+    assert np.array_equal(idx.cpu().numpy(), fi)
+    np.testing.assert_allclose(np.sqrt(d2.cpu().numpy().astype(np.float64)), fd, rtol=1e-5, atol=1e-7)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    c = metrics.chamfer(t(pred), t(gt))
+    assert abs(float(c["chamfer_symmetrical"]) - np.mean([fd.mean(), bd.mean()])) < 1e-7
+    h = metrics.hybrid_chamfer(t(pred), t(gt), t(pred_sim), t(gt_sim))
+    ref_f = np.linalg.norm(pred_sim - gt_sim[fi], axis=1).mean()
+    ref_b = np.linalg.norm(gt_sim - pred_sim[bi], axis=1).mean()
+    assert abs(float(h["hybrid_chamfer_forward"]) - ref_f) < 1e-6 and abs(float(h["hybrid_chamfer_backward"]) - ref_b) < 1e-6
