@@ -26,6 +26,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 (v_mfma_f32_32x32x16_*)
+SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6, "bf16x2": 3}     # matrix-core products per fp32 product (csrc/unet_split.hip)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -39,9 +41,9 @@ def parse():
     ap.add_argument("--grid", type=int, default=128, help="feature-volume edge G (north_star: 128; reference ckpt default: 32)")
     ap.add_argument("--reduce", default="mean", choices=["mean", "max"])
     ap.add_argument("--volume-size", type=int, default=128, help="WNF query volume edge Q")
-    ap.add_argument("--conv-split", type=int, default=0, choices=[0, 2, 3],
-                    help="OPT-IN: run the 3x3x3 convs on the bf16 matrix cores with an exact 2- or 3-plane operand split "
-                         "(csrc/unet_split.hip); 0 = fp32 MFMA (default, the number this bench is quoted on)")
+    ap.add_argument("--conv-mode", default="f16x2", choices=["f16x2", "fp32", "bf16x3", "bf16x2"],
+                    help="arithmetic of the 3x3x3 convs: f16x2 (default; fp32 operands split into two fp16 planes, fp32 accumulation, "
+                         "error vs fp64 below the fp32 kernel's), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (preview quality)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-garments", type=int, default=1)
     return ap.parse_args()
@@ -51,36 +53,40 @@ class ConvTimer:
     """HIP-event brackets around every conv3d launch (on torch's current stream = the launch stream)."""
 
     def __init__(self):
-        self.records = []   # (key, flops, start_event, end_event)
+        self.records = []   # (kernel, flops, bytes, start_event, end_event)
         self.enabled = False
 
     def install(self):
         from garmentnets_amd import ops
-        orig = ops.conv3d_gcr
         timer = self
 
-        def timed(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
-            if not timer.enabled:
-                return orig(src0, src1, a, d, wp, cout, relu, with_stats)
-            B, D, H, W, C0 = src0.shape
-            cin = C0 + (0 if src1 is None else src1.shape[-1])
-            tiles = -(-D // 4) * -(-H // 8) * -(-W // 8)
-            nt = 2 if (cout % 64 == 0 and tiles * (cout // 64) * B >= 1024) else 1
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(src0, src1, a, d, wp, cout, relu, with_stats)
-            e1.record()
-            timer.records.append((nt, 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W + wp.numel() * 4.0, e0, e1))
-            return out
+        def wrap(orig, kernel_name):
+            def timed(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
+                if not timer.enabled:
+                    return orig(src0, src1, a, d, wp, cout, relu, with_stats)
+                B, D, H, W, C0 = src0.shape
+                cin = C0 + (0 if src1 is None else src1.shape[-1])
+                tiles = -(-D // 4) * -(-H // 8) * -(-W // 8)
+                nt = 2 if (cout % 64 == 0 and tiles * (cout // 64) * B >= 1024) else 1
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(src0, src1, a, d, wp, cout, relu, with_stats)
+                e1.record()
+                wbytes = (wp.tensor.numel() * 2.0) if hasattr(wp, "tensor") else wp.numel() * 4.0
+                timer.records.append((kernel_name(nt, wp), 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W + wbytes, e0, e1))
+                return out
+            return timed
 
-        ops.conv3d_gcr = timed
+        ops.conv3d_gcr = wrap(ops.conv3d_gcr, lambda nt, wp: f"conv3d_gcr_kernel<{nt}>")
+        ops.conv3d_gcr_split = wrap(ops.conv3d_gcr_split, lambda nt, wp: "conv3d_split_kernel<%d, %d, %s>" % (
+            nt, 3 if wp.mode == ops.SPLIT_BF16X3 else 2, "true" if wp.mode == ops.SPLIT_F16X2 else "false"))
         import garmentnets_amd.components.unet3d as u
         u.ops = ops
 
     def summary(self):
         groups = {}
-        for nt, flops, byts, e0, e1 in self.records:
-            g = groups.setdefault(nt, dict(flops=0.0, bytes=0.0, ms=0.0, n=0))
+        for name, flops, byts, e0, e1 in self.records:
+            g = groups.setdefault(name, dict(flops=0.0, bytes=0.0, ms=0.0, n=0))
             g["flops"] += flops
             g["bytes"] += byts
             g["ms"] += e0.elapsed_time(e1)
@@ -93,7 +99,7 @@ def measured_traffic(args, kernel):
     separate runs of THIS command, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py) -- only quoted when
     the workload is the one that was profiled."""
     path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-    if not (os.path.exists(path) and (args.batch, args.points, args.grid, args.reduce, args.volume_size) == (16, 6000, 128, "mean", 128)):
+    if not (os.path.exists(path) and (args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode) == (16, 6000, 128, "mean", 128, "f16x2")):
         return None
     k = json.load(open(path))["kernels"].get(kernel)
     return None if k is None else k["hbm_bytes"]
@@ -156,24 +162,8 @@ def main():
     data = Batch(sizes=[args.points] * args.batch, x=x, pos=pos, batch=batch).to(dev)   # resident in HBM before timing
     timer = ConvTimer()
     timer.install()
-    if args.conv_split:
-        from garmentnets_amd import ops as _ops
-        _ops.CONV_SPLIT_PLANES = args.conv_split
-        orig_split = _ops.conv3d_gcr_split
-
-        def timed_split(src0, src1, a, d, wps, planes, cout, relu=True, with_stats=False):
-            if not timer.enabled:
-                return orig_split(src0, src1, a, d, wps, planes, cout, relu, with_stats)
-            B, D, H, W, C0 = src0.shape
-            cin = C0 + (0 if src1 is None else src1.shape[-1])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_split(src0, src1, a, d, wps, planes, cout, relu, with_stats)
-            e1.record()
-            timer.records.append((f"split{planes}", 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W, e0, e1))
-            return out
-
-        _ops.conv3d_gcr_split = timed_split
+    from garmentnets_amd import ops as _ops
+    _ops.CONV_MODE = _ops.CONV_MODE_NAMES[args.conv_mode]
 
     def step():
         return predict_batch(model, data, volume_size=args.volume_size, iso_surface_level=0.5, gradient_sigma=0.5,
@@ -210,26 +200,34 @@ def main():
         groups = timer.summary()
         key = max(groups, key=lambda k: groups[k]["ms"])
         g = groups[key]
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12          # algorithmic (fp32) FLOPs: 54*Cin*Cout per voxel
+        if args.conv_mode == "fp32":
+            peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak"
+        else:
+            n = SPLIT_PRODUCTS[args.conv_mode]
+            peak = PEAK_16BIT_MFMA_TFLOPS / n
+            peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} matrix-core products per algorithmic fp32 product "
+                         f"({args.conv_mode}); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
         line = {
             "metric": "garments/s end-to-end predict (PointNet++ -> gridding -> UNet3D -> WNF decode -> marching cubes)",
             "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not args.conv_split else f"f32 via exact {args.conv_split}-plane bf16 operand split (opt-in)", "data": "synthetic",
+            "dtype": "f32" if args.conv_mode == "fp32" else f"f32 ({args.conv_mode} operand split on the 16-bit matrix cores for the 3x3x3 convs, fp32 accumulation; everything else fp32/fp64)",
+            "data": "synthetic",
             "config": {"workload": f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, "
                                    f"{args.grid}^3 feature volume ({args.reduce}), {args.volume_size}^3 WNF + GGM + MC33 + surface decode",
                        "batch_per_gpu": args.batch, "points": args.points, "grid": args.grid, "reduce": args.reduce,
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level else 0.5,
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": f"conv3d_gcr_kernel<{key}>" if not args.conv_split else f"conv3d_split_kernel<P={args.conv_split}> (fp32-equivalent FLOPs)", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": measured_traffic(args, f"conv3d_gcr_kernel<{key}>"),
+            "roofline": {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_note": peak_note,
+                         "traffic": measured_traffic(args, key),
                          "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["flops"] / g["n"],
                          "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
                          "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "all_conv_instances": {f"conv3d_gcr_kernel<{k}>": {"launches": v["n"], "ms": v["ms"],
-                                                                           "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in groups.items()}},
+                         "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+                                                for k, v in groups.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, hp, sd)

@@ -47,14 +47,14 @@ class SingleConv(PackedModule, nn.Sequential):
         if src1 is not None:
             st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
-        if ops.CONV_SPLIT_PLANES:      # opt-in split-precision matrix-core path (csrc/unet_split.hip)
-            planes = ops.CONV_SPLIT_PLANES
+        if ops.CONV_MODE != ops.CONV_FP32:      # split-operand path on the 16-bit matrix cores (csrc/unet_split.hip)
+            mode = ops.CONV_MODE
             cache = self.__dict__.setdefault("_split_packs", {})
-            key = (planes, self.conv.weight.device, self.conv.weight._version)
+            key = (mode, self.conv.weight.device, self.conv.weight._version)
             if key not in cache:
                 cache.clear()
-                cache[key] = ops.pack_conv_weight_split(self.conv.weight, planes)
-            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], planes, self.conv.out_channels, relu=True, with_stats=with_stats)
+                cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
+            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], self.conv.out_channels, relu=True, with_stats=with_stats)
             return r if with_stats else (r, None)
         if with_stats:
             return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True, with_stats=True)

@@ -6,6 +6,11 @@
 // products, fp32 accumulation, 16x the k-throughput of v_mfma_f32_32x32x2_f32):
 //   P = 3 : 6 products x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1   -> dropped terms <= 2^-24 relative: fp32-class products
 //   P = 2 : 3 products x1w1 + x1w2 + x2w1                       -> 2^-16 relative per product
+// A third mode uses fp16 planes (11-bit significands): x = x1 + x2 leaves <= 2^-22 |x| and the same 3 products drop only
+// x2w2 <= 2^-22 -- half the matrix-core work of bf16 x 3 at an error far below that of the fp32 accumulation of a 27*Cin-term
+// dot product.  fp16's narrow exponent is handled by a power-of-two scale of the weight tensor (max |w| in [1,2), undone
+// exactly in the epilogue); activations are GroupNorm outputs (|x| <= sqrt(group size)*|gamma|+|beta|), values beyond
+// +-65504 would turn into inf and show up as inf/NaN in the output, never as a silently wrong finite number.
 // One bf16 MFMA consumes the 16-channel slice of a tap at once: lane (h = lane>>5, r = lane&31) supplies channels 8h..8h+7
 // of voxel r (A) / of output channel r (B) -- the same fragment the fp32 kernel reads, so the LDS layout is the fp32 one
 // with P bf16 planes per voxel.  The result is validated against the same oracle and goldens as the fp32 path
@@ -29,40 +34,68 @@ struct SplitArgs {
     const float *src1;
     const float *a;
     const float *d;
-    const uint4 *wp;   // [tap][slice][cout][P][16] bf16
+    const uint4 *wp;   // [slice][tap][Cout/32][P][lane 64] x 16 B (8 bf16: channels 8h..8h+7 of cout 32*blk + r, lane = 32h + r), + two zero pad steps
     float *out;
     double *osum;
     double *osq;
     int C0, C1, B, D, H, W, Cout, relu;
     int tiles_y, tiles_x;
+    float out_scale;   // exact power of two undoing the pack's weight scale (1 for the bf16 modes)
 };
 
-__device__ __forceinline__ unsigned bf16_rn_bits(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-// x -> P bf16 planes (exact residual chain); returns the planes' 16-bit patterns
-template <int P>
-__device__ __forceinline__ void split_bf16(float x, unsigned (&pl)[P]) {
-    float r = x;
+// four floats -> P bf16 planes (exact residual chain x = x1 + x2 [+ x3], xi = bf16_rn of the running residual), each plane
+// packed as 4 x bf16 = uint2.  v_cvt_pk_bf16_f32 rounds to nearest even like the host-side pack of the weights.
+template <int P, bool F16>
+__device__ __forceinline__ void split4(float r0, float r1, float r2, float r3, uint2 (&out)[P]) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        pl[i] = bf16_rn_bits(r);
-        r = __fsub_rn(r, __uint_as_float(pl[i] << 16));
+        const f32x2v lo = {r0, r1}, hi = {r2, r3};
+        if (F16) {
+            const f16x2v blo = __builtin_convertvector(lo, f16x2v), bhi = __builtin_convertvector(hi, f16x2v);
+            out[i].x = __builtin_bit_cast(unsigned, blo);
+            out[i].y = __builtin_bit_cast(unsigned, bhi);
+            if (i + 1 < P) {
+                const f32x2v flo = __builtin_convertvector(blo, f32x2v), fhi = __builtin_convertvector(bhi, f32x2v);
+                r0 = __fsub_rn(r0, flo.x); r1 = __fsub_rn(r1, flo.y); r2 = __fsub_rn(r2, fhi.x); r3 = __fsub_rn(r3, fhi.y);
+            }
+            continue;
+        }
+        const bf16x2v blo = __builtin_convertvector(lo, bf16x2v), bhi = __builtin_convertvector(hi, bf16x2v);
+        out[i].x = __builtin_bit_cast(unsigned, blo);
+        out[i].y = __builtin_bit_cast(unsigned, bhi);
+        if (i + 1 < P) {
+            r0 = __fsub_rn(r0, __uint_as_float(out[i].x << 16));
+            r1 = __fsub_rn(r1, __uint_as_float(out[i].x & 0xffff0000u));
+            r2 = __fsub_rn(r2, __uint_as_float(out[i].y << 16));
+            r3 = __fsub_rn(r3, __uint_as_float(out[i].y & 0xffff0000u));
+        }
     }
 }
 
-template <int NT, int P>
+template <bool F16>
+__device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const f32x16s &c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NT, int P, bool F16>
 __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     constexpr int CT = NT * 32;
-    // bytes per voxel / per weight row in LDS.  P = 2: 64 + 16 pad (16-byte slots rotate with the row, conflict-free b128);
-    // P = 3: 96 unpadded (2-way conflicts) so that halo + weights stay under 80 KB and two workgroups share a CU
-    constexpr int VB = (P == 3) ? 96 : P * 32 + 16;
-    __shared__ __attribute__((aligned(16))) unsigned char halo[SP_HVOX * VB];
-    __shared__ __attribute__((aligned(16))) unsigned char wsm[2][CT * VB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
+    // LDS (ONE array: a second __shared__ object makes hipcc drain the LDS-DMA queue before every ds_read):
+    //   halo : 600 voxels x VB bytes, VB = P planes of 16 bf16 + one 16-byte pad slot (odd slot stride: voxels rotate over the banks)
+    //   ring : 2 x (NT*P) B fragments of 1 KB in lane order, filled by global_load_lds_dwordx4 two taps ahead
+    constexpr int VB = P * 32 + 16;
+    constexpr int HALO_BYTES = SP_HVOX * VB;
+    constexpr int BTAP = NT * P * 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HALO_BYTES + 2 * BTAP];
+    unsigned char *const halo = smem;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C0 + p.C1;
     // XCD-aware work-item order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks a CONTIGUOUS
     // range of (tile, column block) pairs, column blocks of one tile adjacent, tiles in z-fastest order -> the halo overlap of
@@ -72,7 +105,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     const int ncb = p.Cout / CT;
     int tile = (int)(logical / (unsigned)ncb);
     const int cb = (int)(logical % (unsigned)ncb);
-    // z-fastest tile order: the z halo is the fattest (2 of 6 slices), so tiles adjacent in z run back to back
     const int tiles_z = (p.D + 3) / 4;
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
@@ -92,85 +124,98 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 
     const int abase = ((wave * SP_HY + (r >> 3)) * SP_HX + (r & 7)) * VB + 16 * h;   // bytes; plane pl at +32*pl
     constexpr int AF1 = 4 * SP_HX * VB;
-    const int bbase = r * VB + 16 * h;
-
-    constexpr int WV = CT * P * 2;                        // uint4 per weight tile
-    constexpr int WPT = (WV + 255) / 256;
     const int nslices = Cin / SP_KS;
-    const int64_t tap_stride = (int64_t)nslices * p.Cout * P * 2;   // uint4 units
+    // B operands: the pack is in fragment order [slice][tap][Cout/32][plane][lane] (16 B per lane), so the NT*P fragments a
+    // workgroup needs for one (slice, tap) step are NT*P contiguous KB.  They are DMA'd into the ring (global_load_lds: no
+    // VGPRs, one wave per 1-KB fragment, round robin) two steps ahead and read back in lane order (conflict-free b128).
+    const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;                          // bytes per (slice, tap) step
+    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + lane * 16;
+#define SP_ISSUE_B(SLOT_OFF, ROT)                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NT * P; ++c)                                                                         \
+        if (((c + (ROT)) & 3) == wave)                                                                                         \
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bg + c * 1024), reinterpret_cast<unsigned *>(smem + HALO_BYTES + (SLOT_OFF) + c * 1024), 16, 0, 0);
+    SP_ISSUE_B(0, 0)
+    bg += bstep;
+    SP_ISSUE_B(BTAP, 1)
+    bg += bstep;                                   // bg -> step j + 2 from here on
 
     for (int s = 0; s < nslices; ++s) {
         const int c0 = s * SP_KS;
-        {   // ---- halo stage: GroupNorm affine, then exact split into P bf16 planes
+        // (every halo read of the previous slice completed before its last tap's barrier: the halo can be overwritten)
+        {   // ---- halo stage: GroupNorm affine, then exact split into P bf16 planes.  All the tile's loads are issued before the
+            //      first use (one exposed latency per slice), the other workgroup of the CU computes meanwhile
             const bool from1 = c0 >= p.C0;
             const float *src = from1 ? p.src1 : p.src0;
             const int Cs = from1 ? p.C1 : p.C0;
             const int cs = from1 ? c0 - p.C0 : c0;
             const float *ab = p.a + (int64_t)b * Cin + c0;
             const float *db = p.d + (int64_t)b * Cin + c0;
-            for (int idx = tid; idx < SP_HVOX * 4; idx += 256) {
-                const int hv = idx >> 2, c4 = (idx & 3) * 4;
+            constexpr int NIT = (SP_HVOX * 4 + 255) / 256;
+            const int c4 = (tid & 3) * 4;                                  // 256 % 4 == 0: the same channel quad every iteration
+            const float4 av = *reinterpret_cast<const float4 *>(ab + c4);
+            const float4 dv = *reinterpret_cast<const float4 *>(db + c4);
+            float4 raw[NIT];
+            bool inb[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                const int hv = idx >> 2;
                 const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
                 const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                inb[it] = idx < SP_HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inb[it]) {
                     int64_t off;
                     if (from1) off = ((((int64_t)b * D1 + (gz >> 1)) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * Cs + cs + c4;
                     else off = ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * Cs + cs + c4;
-                    const float4 xin = *reinterpret_cast<const float4 *>(src + off);
-                    const float4 av = *reinterpret_cast<const float4 *>(ab + c4);
-                    const float4 dv = *reinterpret_cast<const float4 *>(db + c4);
-                    v[0] = __fadd_rn(__fmul_rn(xin.x, av.x), dv.x);
-                    v[1] = __fadd_rn(__fmul_rn(xin.y, av.y), dv.y);
-                    v[2] = __fadd_rn(__fmul_rn(xin.z, av.z), dv.z);
-                    v[3] = __fadd_rn(__fmul_rn(xin.w, av.w), dv.w);
+                    raw[it] = *reinterpret_cast<const float4 *>(src + off);
                 }
-                unsigned pl[4][P];
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split_bf16<P>(v[e], pl[e]);
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < SP_HVOX * 4) {
+                    const int hv = idx >> 2;
+                    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                    if (inb[it]) {                                          // zero padding comes AFTER the affine
+                        v0 = __fadd_rn(__fmul_rn(raw[it].x, av.x), dv.x);
+                        v1 = __fadd_rn(__fmul_rn(raw[it].y, av.y), dv.y);
+                        v2 = __fadd_rn(__fmul_rn(raw[it].z, av.z), dv.z);
+                        v3 = __fadd_rn(__fmul_rn(raw[it].w, av.w), dv.w);
+                    }
+                    uint2 pl[P];
+                    split4<P, F16>(v0, v1, v2, v3, pl);
 #pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    uint2 w2;
-                    w2.x = pl[0][i] | (pl[1][i] << 16);
-                    w2.y = pl[2][i] | (pl[3][i] << 16);
-                    *reinterpret_cast<uint2 *>(halo + hv * VB + i * 32 + c4 * 2) = w2;
+                    for (int i = 0; i < P; ++i) *reinterpret_cast<uint2 *>(halo + hv * VB + i * 32 + c4 * 2) = pl[i];
                 }
             }
         }
-        const uint4 *wslice = p.wp + ((int64_t)s * p.Cout + n0) * (P * 2);
-        uint4 wreg[WPT];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < WV) {
-                wreg[i] = wslice[idx];
-                *reinterpret_cast<uint4 *>(&wsm[0][(idx / (P * 2)) * VB + (idx % (P * 2)) * 16]) = wreg[i];
-            }
-        }
-        __syncthreads();
-        uint4 a0[P], a1[P], na0[P], na1[P];
+        __syncthreads();                            // halo visible (and this wave's outstanding ring DMAs have landed)
+        // ring slot of step j = s*27 + tap is j & 1 = (s & 1) ^ (tap & 1)   (27 is odd)
+        const int slot_e = (s & 1) * BTAP, slot_o = BTAP - slot_e;         // byte offsets of the slots of even / odd taps
+        const unsigned char *const ring_rd = smem + HALO_BYTES + lane * 16;
+        uint4 a0[P], a1[P], na0[P], na1[P], bf[NT][P], nbf[NT][P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            a0[i] = *reinterpret_cast<const uint4 *>(halo + abase + i * 32);
-            a1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + i * 32);
-            na0[i] = a0[i]; na1[i] = a1[i];
+            na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + i * 32);
+            na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + i * 32);
         }
-        for (int tap = 0; tap < 27; ++tap) {
-            const int cur = tap & 1;
-            const bool more = tap + 1 < 27;
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < WV) wreg[i] = wslice[(int64_t)(tap + 1) * tap_stride + idx];
-                }
-            }
-            uint4 bf[NT][P];
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + slot_e + (u * P + i) * 1024);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int slot_cur = (tap & 1) ? slot_o : slot_e, slot_nxt = (tap & 1) ? slot_e : slot_o;
+#pragma unroll
+            for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
 #pragma unroll
             for (int u = 0; u < NT; ++u)
 #pragma unroll
-                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(&wsm[cur][bbase + u * 32 * VB + i * 32]);
-            if (more) {
+                for (int i = 0; i < P; ++i) bf[u][i] = nbf[u][i];
+            // every wave holds step j's fragments in registers and its DMA share of step j+1 has landed
+            __syncthreads();
+            if (tap + 1 < 27) {
                 const int t1 = tap + 1;
                 const int toff = (((t1 / 9) * SP_HY + (t1 / 3) % 3) * SP_HX + t1 % 3) * VB;
 #pragma unroll
@@ -178,29 +223,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                     na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + toff + i * 32);
                     na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + toff + i * 32);
                 }
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + slot_nxt + (u * P + i) * 1024);
             }
+            SP_ISSUE_B(slot_cur, tap)               // step j+2 overwrites step j's slot (read by everyone before the barrier)
+            bg += bstep;
             __builtin_amdgcn_sched_barrier(0);
 #define SP_PROD(IA, IB)                                                                                                        \
             _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
-                acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[IA]), __builtin_bit_cast(bf16x8, bf[u][IB]), acc[0][u], 0, 0, 0); \
-                acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[IA]), __builtin_bit_cast(bf16x8, bf[u][IB]), acc[1][u], 0, 0, 0); \
+                acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                        \
+                acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                        \
             }
             // smallest terms first
             if (P == 3) { SP_PROD(P - 1, 0) SP_PROD(1, P - 2) SP_PROD(0, P - 1) }
             SP_PROD(1, 0) SP_PROD(0, 1) SP_PROD(0, 0)
 #undef SP_PROD
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < WV) *reinterpret_cast<uint4 *>(&wsm[cur ^ 1][(idx / (P * 2)) * VB + (idx % (P * 2)) * 16]) = wreg[i];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
         }
+        // tap 26 prefetched nothing: step j+1's fragments are read after the next slice's staging barrier; the last tap's own
+        // barrier is the point after which no wave reads this slice's halo any more
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -208,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
     }
+#undef SP_ISSUE_B
+    __syncthreads();                                // drains the two pad-step DMAs; the epilogue reuses the halo as scratch
     // ---- epilogue (identical to the fp32 kernel)
     const int gz = z0 + wave;
     float ssum[NT], ssq[NT];
@@ -223,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = tot[t][u][q];
+                    float v = __fmul_rn(tot[t][u][q], p.out_scale);
                     if (p.relu) v = fmaxf(v, 0.f);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
@@ -249,10 +294,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 }
 
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                                   const void *wp_planes, int planes, int B, int D, int H, int W, int Cout, int relu, float *out,
-                                   double *out_sum, double *out_sumsq, void *stream) {
+                                   const void *wp_planes, int mode, float out_scale, int B, int D, int H, int W, int Cout, int relu,
+                                   float *out, double *out_sum, double *out_sumsq, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
-    GN_REQUIRE(planes == 2 || planes == 3, "gn_conv3d_gcr_split: planes must be 2 or 3");
+    GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
+    GN_REQUIRE(out_scale > 0.f, "gn_conv3d_gcr_split: out_scale must be positive (1 for the bf16 modes)");
     GN_REQUIRE(C0 % SP_KS == 0 && C1 % SP_KS == 0 && Cout % 32 == 0, "gn_conv3d_gcr_split: channel counts must be multiples of 16 (in) / 32 (out)");
     GN_REQUIRE(C1 == 0 || (src1 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: upsampled source needs even dims");
     GN_REQUIRE((out_sum == nullptr) == (out_sumsq == nullptr), "gn_conv3d_gcr_split: out_sum and out_sumsq must come together");
@@ -264,19 +310,21 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     }
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
-    p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu;
+    p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale;
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
-    if (planes == 3) {
-        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 3>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_kernel<1, 3>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
-    } else {
-        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, 2>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_kernel<1, 2>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
-    }
+#define SP_LAUNCH(P_, F16_)                                                                                                    \
+    do {                                                                                                                       \
+        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, P_, F16_>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);   \
+        else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);        \
+    } while (0)
+    if (mode == GN_SPLIT_BF16X3) SP_LAUNCH(3, false);
+    else if (mode == GN_SPLIT_BF16X2) SP_LAUNCH(2, false);
+    else SP_LAUNCH(2, true);
+#undef SP_LAUNCH
     GN_LAUNCH_CHECK("gn_conv3d_gcr_split");
     return GN_OK;
 }

@@ -5,6 +5,7 @@ current torch stream.  Tensors must live on a ROCm device -- there is no CPU pat
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -209,30 +210,60 @@ def pack_conv_weight(w):
     return w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2).contiguous()
 
 
-# Opt-in split-precision convolution (0 = fp32 MFMA, the default and the only mode bench.py measures unless asked;
-# 2 / 3 = bf16 planes per operand, see csrc/unet_split.hip).
-CONV_SPLIT_PLANES = 0
+CONV_FP32, SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2 = 0, 2, 3, 4          # 2..4 = GN_SPLIT_* of include/garmentnets_hip.h
+CONV_MODE_NAMES = {"fp32": CONV_FP32, "f16x2": SPLIT_F16X2, "bf16x3": SPLIT_BF16X3, "bf16x2": SPLIT_BF16X2}
+# Arithmetic of the 3x3x3 convolutions (components/unet3d.py reads this on every call):
+#   f16x2  (default) fp32 operands split into two fp16 planes, 3 products on the 16-bit matrix cores, fp32 accumulation
+#          (csrc/unet_split.hip) -- measured error against fp64 is BELOW the fp32-MFMA kernel's (fewer accumulation roundings)
+#   fp32   v_mfma_f32_32x32x2_f32 (csrc/unet.hip): exact fp32 products, 1/16 of the matrix-core rate
+#   bf16x3 / bf16x2: bf16 planes, 6 / 3 products (fp32-class / preview quality)
+CONV_MODE = CONV_MODE_NAMES[os.environ.get("GARMENTNETS_CONV_MODE", "f16x2")]
 
 
-def pack_conv_weight_split(w, planes):
-    """(Cout, Cin, 3,3,3) fp32 -> exact bf16 plane decomposition packed [27][Cin/16][Cout][planes][16] (int16 bit patterns)."""
+class SplitPack:
+    """weight planes of the split-precision conv: .tensor (int16 bit patterns, MFMA-fragment order), .mode, .out_scale"""
+
+    def __init__(self, tensor, mode, out_scale):
+        self.tensor, self.mode, self.out_scale = tensor, int(mode), float(out_scale)
+
+    def to(self, device):
+        return SplitPack(self.tensor.to(device), self.mode, self.out_scale)
+
+
+def pack_conv_weight_split(w, mode):
+    """(Cout, Cin, 3,3,3) fp32 -> exact plane decomposition (w = w1 + w2 [+ w3], residual chain) in MFMA-fragment order
+    [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by two zero
+    (slice, tap) steps: the kernel's fragment DMA runs two steps ahead.  mode SPLIT_BF16X2/3: bf16 planes;
+    SPLIT_F16X2: two fp16 planes of w * 2^k, k chosen so that max|w| * 2^k is in [1, 2) (out_scale = 2^-k undoes it exactly)."""
+    if mode not in (SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2):
+        raise ValueError(f"unknown split mode {mode}")
     cout, cin = w.shape[:2]
-    base = w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2)   # [27][S][Cout][16]
+    w = w.detach().float()
+    planes, dt, scale = (2, torch.float16, 1.0) if mode == SPLIT_F16X2 else (int(mode), torch.bfloat16, 1.0)
+    if mode == SPLIT_F16X2:
+        m = float(w.abs().max())
+        if m > 0 and math.isfinite(m):
+            scale = 2.0 ** (-math.floor(math.log2(m)))
+    base = (w * scale).permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 2, 8, cout // 32, 32)                # [tap][S][h][8][blk][r]
+    base = base.permute(1, 0, 4, 2, 5, 3)                                                                # [S][tap][blk][h][r][8]
     out, r = [], base
     for _ in range(planes):
-        p = r.to(torch.bfloat16)
+        p = r.to(dt)
         out.append(p)
         r = r - p.float()
-    return torch.stack(out, dim=3).contiguous().view(torch.int16)          # [27][S][Cout][planes][16]
+    pk = torch.stack(out, dim=3).contiguous()                                                            # [S][tap][blk][planes][h][r][8]
+    pk = pk.reshape(cin // 16 * 27, -1)
+    pk = torch.cat([pk, torch.zeros_like(pk[:2])], dim=0)
+    return SplitPack(pk.contiguous().view(torch.int16), mode, 1.0 / scale)
 
 
-def conv3d_gcr_split(src0, src1, a, d, wps, planes, cout, relu=True, with_stats=False):
+def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
-    _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(wps), int(planes), B, D, H, W, cout, 1 if relu else 0,
-              _p(out), _p(s), _p(q), _stream())
+    _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, pack.out_scale, B, D, H, W, cout,
+              1 if relu else 0, _p(out), _p(s), _p(q), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

@@ -145,11 +145,19 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
                   double *out_sumsq, void *stream);
 
 /* OPT-IN split-precision variant of gn_conv3d_gcr (never used unless the host asks for it): identical contract, but the
- * fp32 operands are decomposed exactly into `planes` (2 or 3) bf16 planes and multiplied on the bf16 matrix cores with fp32
- * accumulation (3 resp. 6 partial products; planes = 3 drops only terms <= 2^-24 relative).  wp_planes: bf16 weight pack
- * [27 taps][Cin/16][Cout][planes][16] (garmentnets_amd.ops.pack_conv_weight_split). */
+ * fp32 operands are decomposed into low-precision planes (x = x1 + x2 [+ x3], exact residual chain) and multiplied on the
+ * 16-bit matrix cores with fp32 accumulation:
+ *   GN_SPLIT_BF16X3: 3 bf16 planes, 6 partial products, dropped terms <= 2^-24 relative (fp32-class products)
+ *   GN_SPLIT_F16X2 : 2 fp16 planes, 3 partial products, operand residual and dropped term <= 2^-22 relative
+ *   GN_SPLIT_BF16X2: 2 bf16 planes, 3 partial products, 2^-16 relative (fast preview quality)
+ * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + two zero steps
+ * (garmentnets_amd.ops.pack_conv_weight_split); out_scale: the exact power of two that undoes the pack's weight scale
+ * (fp16 mode; 1 for bf16). */
+#define GN_SPLIT_BF16X2 2
+#define GN_SPLIT_BF16X3 3
+#define GN_SPLIT_F16X2 4
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                        const void *wp_planes, int planes, int B, int D, int H, int W, int Cout, int relu, float *out,
+                        const void *wp_planes, int mode, float out_scale, int B, int D, int H, int W, int Cout, int relu, float *out,
                         double *out_sum, double *out_sumsq, void *stream);
 
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
