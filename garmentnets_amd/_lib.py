@@ -44,6 +44,7 @@ PROTOTYPES = {
     "gn_mc33": [_vp, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "gn_gather_nn": [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _vp, _vp],
     "gn_scale_verts": [_vp, _i64, _f64, _vp, _vp],
+    "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
 _RESTYPES = {"gn_mc33_workspace_bytes": _sz}

@@ -1,0 +1,258 @@
+// decode_split.hip -- the implicit decoder MLP [128, 256, 256, OUT<=4] on the 16-bit matrix cores (gn_implicit_decode_split).
+//
+// Same layer semantics as implicit_decode_kernel (decode.hip; ImplicitWNFDecoder.forward, networks/conv_implicit_wnf.py:128-149):
+// y = bn(relu(x W^T + b)) three times, on PRE-SAMPLED feature rows; the BatchNorm affine of a hidden layer is folded into the
+// NEXT layer's weights and bias on the host (W' = W diag(s), b' = b + W t: exact algebra, evaluated in fp64).  Arithmetic as in unet_split.hip's f16x2 mode: every fp32
+// operand is split into two fp16 planes (x = x1 + x2, residual <= 2^-22 |x|), three MFMA products per fp32 product
+// (x1w2 + x2w1 + x1w1, v_mfma_f32_32x32x16_f16, fp32 accumulation); the weights carry a power-of-two scale per layer (max |w| in
+// [1, 2)) that the epilogue undoes exactly.
+//
+// Structure (nothing in common with the fp32 kernel):
+//  * TRANSPOSED chain, activations never leave the registers.  A wave owns 32 queries and computes H^T[units][32 q] =
+//    W[units][K] . X^T[K][32 q]: the weights are the A operand, the activations the B operand.  The D fragment of a 32-unit
+//    block holds, per lane (h = lane>>5, r = lane&31 = query), units 4h + {0..3, 8..11} (registers 0-7) and 4h + {16..19, 24..27}
+//    (registers 8-15) -- exactly the 8 k-values per lane a B fragment of the NEXT layer needs, for two 16-deep k groups, once
+//    the next layer's weight rows are packed in that k order (host side: ops.pack_decode_split).  So bias/ReLU and the fp16
+//    split are applied to the accumulators in place and the result is the next layer's B operand: no LDS round trip, no barrier.
+//  * The weights (384 KB of fp16 planes, shared by every query) stream through a 4-stage LDS ring filled by
+//    global_load_lds_dwordx4 three stages ahead (stage = 16 KB = one pair of 32-unit blocks x 4 k-groups = 24 MFMAs per wave),
+//    one raw s_barrier + counted vmcnt per stage.  A workgroup (4 waves = 128 queries) is persistent: it walks tiles
+//    blockIdx.x, +gridDim.x, ... and the ring simply wraps, so only the first stages of a launch are exposed.
+//  * One wave per SIMD (launch_bounds(256, 1)): X0 planes 64 + H1 planes 128 + accumulators 32 + A fragments 32 + the next
+//    tile's rows 64 VGPRs.
+#include "common.h"
+
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2q __attribute__((ext_vector_type(2)));
+
+#define DS_K0 128
+#define DS_N 256
+#define DS_STAGE_BYTES 16384
+#define DS_NSTAGE 24                 // 8 (layer 1: 4 block pairs x 2 k-halves) + 16 (layer 2: 4 block pairs x 4 k-quarters)
+#define DS_RING 4
+#define DS_TILE 128                  // queries per workgroup pass
+
+struct DecSplitArgs {
+    const float *xin; int ldxin; long long M;
+    const unsigned char *wp;         // [24 stages][4 k-groups][2 blocks][2 planes][64 lanes] x 16 B
+    const float *tab;                // tab1 [8][2][16] (b1) | tab2 [8][2][1+OUT][16] (b2', w3') | b3', s3, t3 [3][OUT]
+    float inv1, inv2;                // exact powers of two undoing the weight scales
+    float *out; int ldo;
+};
+
+__device__ __forceinline__ void ds_split2(float a, float b, unsigned &p1, unsigned &p2) {
+    const f32x2q v = {a, b};
+    const h16x2 x1 = __builtin_convertvector(v, h16x2);
+    const f32x2q back = __builtin_convertvector(x1, f32x2q);
+    const f32x2q res = {__fsub_rn(a, back.x), __fsub_rn(b, back.y)};
+    const h16x2 x2 = __builtin_convertvector(res, h16x2);
+    p1 = __builtin_bit_cast(unsigned, x1);
+    p2 = __builtin_bit_cast(unsigned, x2);
+}
+
+__device__ __forceinline__ f32x16q ds_mfma(const uint4 &a, const uint4 &b, const f32x16q &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// The weight DMA is issued from inline asm ON PURPOSE: hipcc (ROCm 7.2) guards every ds_read that follows a
+// __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0) (it cannot prove the read does not alias the DMA's LDS
+// destination), which would drain the three-stage-deep ring at every k-group.  Slot reuse is made safe by hand instead: the
+// counted s_waitcnt + s_barrier of the stage hand-over.  Measured (262144 rows): 0.165 ms with the asm DMA, 0.201 ms with the
+// builtin, 0.545 ms for the fp32-MFMA kernel.  (m0 = LDS byte address of the wave's 1-KB destination; lane i lands at
+// +16 i.  Nothing else in this kernel uses m0.)
+__device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); expcnt left at 7 (no wait)
+#define DS_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
+
+template <int OUTC>
+__global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitArgs p) {
+    constexpr int TAB1 = 8 * 2 * 16, TAB2 = 8 * 2 * (1 + OUTC) * 16, TABN = TAB1 + TAB2 + 3 * OUTC;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DS_RING * DS_STAGE_BYTES + ((TABN * 4 + 15) / 16) * 16];
+    float *const tab = reinterpret_cast<float *>(smem + DS_RING * DS_STAGE_BYTES);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
+
+    for (int i = tid; i < TABN; i += 256) tab[i] = p.tab[i];
+
+    // each wave DMAs 4 of a stage's 16 fragments
+    const unsigned char *wsrc = p.wp + (wave * 4) * 1024 + lane * 16;
+#define DS_ISSUE(STAGE, SLOT)                                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
+        ds_glds16(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
+    DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2) DS_ISSUE(3, 3)
+
+    // first tile's rows: lane (h, r) holds the 8 channels 16g + 8h .. + 7 of query r for g = 0..7
+    float4 raw[16];
+    {
+        long long m = (long long)blockIdx.x * DS_TILE + wave * 32 + r;
+        if (m >= p.M) m = p.M - 1;
+        const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): prologue DMAs + table stores
+    __syncthreads();
+
+    const unsigned char *const ring_rd = smem + lane * 16;
+    uint4 A[4], nA[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + f * 1024);
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- X0 planes from the prefetched rows
+        uint4 x0[2][8], h1[2][16];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            ds_split2(raw[2 * g].x, raw[2 * g].y, x0[0][g].x, x0[1][g].x);
+            ds_split2(raw[2 * g].z, raw[2 * g].w, x0[0][g].y, x0[1][g].y);
+            ds_split2(raw[2 * g + 1].x, raw[2 * g + 1].y, x0[0][g].z, x0[1][g].z);
+            ds_split2(raw[2 * g + 1].z, raw[2 * g + 1].w, x0[0][g].w, x0[1][g].w);
+        }
+        float psum[OUTC];
+#pragma unroll
+        for (int o = 0; o < OUTC; ++o) psum[o] = 0.f;
+        // two accumulator sets: the epilogue of block pair P-1 (VALU) is spread over the MFMAs of pair P's first stage
+        f32x16q acc[2][2];
+
+        // epilogue chunk c (registers 4c..4c+3 of both blocks) of block pair P (0-3: layer 1, 4-7: layer 2)
+        auto epilogue = [&](int P, int c) {
+            const int set = P & 1;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                if (P < 4) {
+                    const int nb = 2 * P + blk;
+                    const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * c);
+                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * c + 0], p.inv1, bv.x), 0.f);
+                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * c + 1], p.inv1, bv.y), 0.f);
+                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * c + 2], p.inv1, bv.z), 0.f);
+                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * c + 3], p.inv1, bv.w), 0.f);
+                    // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; chunk c fills half a fragment
+                    const int g2 = 2 * nb + (c >> 1);
+                    if (c & 1) {
+                        ds_split2(v0, v1, h1[0][g2].z, h1[1][g2].z);
+                        ds_split2(v2, v3, h1[0][g2].w, h1[1][g2].w);
+                    } else {
+                        ds_split2(v0, v1, h1[0][g2].x, h1[1][g2].x);
+                        ds_split2(v2, v3, h1[0][g2].y, h1[1][g2].y);
+                    }
+                } else {
+                    const int nb = 2 * (P - 4) + blk;
+                    const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * c;
+                    const float4 bv = *reinterpret_cast<const float4 *>(tb);
+                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * c + 0], p.inv2, bv.x), 0.f);
+                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * c + 1], p.inv2, bv.y), 0.f);
+                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * c + 2], p.inv2, bv.z), 0.f);
+                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * c + 3], p.inv2, bv.w), 0.f);
+#pragma unroll
+                    for (int o = 0; o < OUTC; ++o) {
+                        const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
+                        psum[o] = fmaf(v0, wv.x, psum[o]);
+                        psum[o] = fmaf(v1, wv.y, psum[o]);
+                        psum[o] = fmaf(v2, wv.z, psum[o]);
+                        psum[o] = fmaf(v3, wv.w, psum[o]);
+                    }
+                }
+            }
+        };
+
+#pragma unroll
+        for (int t = 0; t < DS_NSTAGE; ++t) {
+            const bool l1 = t < 8;
+            const int P = l1 ? (t >> 1) : 4 + ((t - 8) >> 2);              // block pair
+            const int kq = l1 ? (t & 1) : ((t - 8) & 3);                   // k-quarter (4 k-groups)
+            const int set = P & 1;
+            if (kq == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { acc[set][0][q] = 0.f; acc[set][1][q] = 0.f; }
+            }
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) A[f] = nA[f];
+                if (kg < 3) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + (t % DS_RING) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
+                } else {
+                    // ---- stage hand-over: stage t+1 has landed for everybody, stage t has been read by everybody
+                    // VM queue (oldest first): stage t+1, t+2, t+3 [+ the 16 row loads issued in stage 16]; see the note below
+                    if (t >= 17 && t <= 19) DS_WAIT_VM_LGKM0(24); else DS_WAIT_VM_LGKM0(8);
+                    __builtin_amdgcn_s_barrier();
+                    DS_ISSUE((t + 4) % DS_NSTAGE, t % DS_RING)
+                    if (t == 16) {                                        // next tile's rows (clamped: the last tile re-reads its own)
+                        long long tn = tile + gridDim.x;
+                        if (tn >= ntiles) tn = tile;
+                        long long m = tn * DS_TILE + wave * 32 + r;
+                        if (m >= p.M) m = p.M - 1;
+                        const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1) % DS_RING) * DS_STAGE_BYTES + f * 1024);
+                }
+                const int g = kq * 4 + kg;
+                const uint4 b1 = l1 ? x0[0][g & 7] : h1[0][g], b2 = l1 ? x0[1][g & 7] : h1[1][g];
+                // A: [blk0 w1, blk0 w2, blk1 w1, blk1 w2]; smallest terms first
+                acc[set][0] = ds_mfma(A[1], b1, acc[set][0]);
+                acc[set][1] = ds_mfma(A[3], b1, acc[set][1]);
+                acc[set][0] = ds_mfma(A[0], b2, acc[set][0]);
+                acc[set][1] = ds_mfma(A[2], b2, acc[set][1]);
+                acc[set][0] = ds_mfma(A[0], b1, acc[set][0]);
+                acc[set][1] = ds_mfma(A[2], b1, acc[set][1]);
+                if (kq == 0 && P > 0) epilogue(P - 1, kg);                // the previous pair's epilogue rides along
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) epilogue(7, c);
+        // ---- output layer: the two lane halves hold disjoint unit sets of the same query
+        const long long m = tile * DS_TILE + wave * 32 + r;
+#pragma unroll
+        for (int o = 0; o < OUTC; ++o) {
+            const float s = psum[o] + __shfl_xor(psum[o], 32);
+            if (h == 0 && m < p.M) {
+                const float *t3 = tab + TAB1 + TAB2;
+                float y = fmaxf(__fadd_rn(s, t3[o]), 0.f);
+                y = __fadd_rn(__fmul_rn(y, t3[OUTC + o]), t3[2 * OUTC + o]);
+                p.out[m * p.ldo + o] = y;
+            }
+        }
+    }
+#undef DS_ISSUE
+    __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the wrapped-around DMAs must land before the LDS goes away
+    __syncthreads();
+}
+// Note on the counted waits.  VM operations retire in issue order.  At the hand-over of stage t the queue holds the DMAs of
+// stages t+1, t+2, t+3 (4 per wave each); stage t+1 has landed when at most 8 remain.  The 16 row loads of the next tile are
+// issued right after the DMAs of stage 20 (at the hand-over of stage 16), i.e. they sit between stage 20's and stage 21's DMAs:
+// for t = 17, 18, 19 they are younger than stage t+1, so 8 + 16 may remain; from t = 20 on they are older than the stage
+// being waited for and the plain count applies again (they had four stages = 24 x 4 MFMAs to arrive).
+
+extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, float inv1, float inv2,
+                                        int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
+    GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
+    GN_REQUIRE(C0 == DS_K0 && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_split: only the [128,256,256,out] decoder is packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
+    GN_REQUIRE(ldxin >= C0 && ldxin % 4 == 0, "gn_implicit_decode_split: rows need a 16-byte aligned leading dimension");
+    GN_REQUIRE(inv1 > 0.f && inv2 > 0.f, "gn_implicit_decode_split: bad weight scales");
+    if (M == 0) return GN_OK;
+    GN_REQUIRE(xin && wpack && tab && out, "gn_implicit_decode_split: null pointer");
+    DecSplitArgs p;
+    p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.inv1 = inv1; p.inv2 = inv2; p.out = out; p.ldo = ldo;
+    const int64_t ntiles = gn_cdiv(M, DS_TILE);
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);      // one persistent workgroup per CU
+    hipStream_t st = gn_stream(stream);
+    switch (OUT) {
+        case 1: hipLaunchKernelGGL(implicit_decode_split_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(implicit_decode_split_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(implicit_decode_split_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(implicit_decode_split_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+    }
+    GN_LAUNCH_CHECK("gn_implicit_decode_split");
+    return GN_OK;
+}

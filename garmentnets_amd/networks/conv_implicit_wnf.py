@@ -77,13 +77,16 @@ class ImplicitWNFDecoder(PackedModule):
         ch = self.nn_channels
         if not (len(ch) == 4 and ch[0] % 32 == 0 and ch[1] % 256 == 0 and ch[2] % 256 == 0 and ch[3] <= 4):
             return None
-        layers = []
+        layers, raw = [], []
         for i, block in enumerate(self.mlp):
             w = block[0].weight.detach().float()
             b = block[0].bias.detach().float().contiguous()
             sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
             layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
-        return tuple(layers)
+            raw.append((w, b, sc, sh))
+        # the shipped [128,256,256,out] decoder also gets the split-operand pack (csrc/decode_split.hip, ops.DECODE_MODE)
+        split = ops.pack_decode_split(raw).to(w.device) if tuple(ch[:3]) == (128, 256, 256) else None
+        return tuple(layers) + (split,)
 
     def _decode_rows(self, vol_b, out, query=None, Q=0):
         M = out.shape[0]
@@ -95,8 +98,10 @@ class ImplicitWNFDecoder(PackedModule):
                 s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m], out=buf[:m])
             else:
                 s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m, out=buf[:m])
-            if layers is not None:
-                ops.implicit_decode(None, layers, M=m, out=out[m0:m0 + m], xin=s)
+            if layers is not None and layers[3] is not None and ops.DECODE_MODE == "f16x2":
+                ops.implicit_decode_split(s, layers[3], out=out[m0:m0 + m])
+            elif layers is not None:
+                ops.implicit_decode(None, layers[:3], M=m, out=out[m0:m0 + m], xin=s)
             else:
                 out[m0:m0 + m] = self.mlp(s)
 

@@ -334,6 +334,81 @@ def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=
     return out
 
 
+# decoder MLP arithmetic: "f16x2" (default; csrc/decode_split.hip, same operand split as the convs) or "fp32" (csrc/decode.hip)
+DECODE_MODE = os.environ.get("GARMENTNETS_DECODE_MODE", "f16x2")
+
+
+class DecodeSplitPack:
+    """weights / epilogue tables of gn_implicit_decode_split for one [128, 256, 256, OUT] decoder"""
+
+    def __init__(self, wpack, tab, inv1, inv2, out_channels):
+        self.wpack, self.tab, self.inv1, self.inv2, self.out_channels = wpack, tab, float(inv1), float(inv2), int(out_channels)
+
+    def to(self, device):
+        return DecodeSplitPack(self.wpack.to(device), self.tab.to(device), self.inv1, self.inv2, self.out_channels)
+
+
+def _pow2_scale(w):
+    m = float(w.abs().max())
+    return 2.0 ** (-math.floor(math.log2(m))) if (m > 0 and math.isfinite(m)) else 1.0
+
+
+def _d_unit(q, h):
+    """hidden unit (within a 32-unit block) held by accumulator register q of lane half h (32x32 MFMA D layout)"""
+    return (q & 3) + 8 * (q >> 2) + 4 * h
+
+
+def pack_decode_split(layers):
+    """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)) with w1 (256,128), w2 (256,256), w3 (OUT,256) fp32, s/t = folded
+    BatchNorm scale/shift or None -> DecodeSplitPack.  The BatchNorm affine of hidden layer i is folded into layer i+1
+    (W' = W diag(s), b' = b + W t, in fp64).  Weight stages: [24][4 k-groups][2 blocks][2 planes][64 lanes][8 fp16]; layer 2's k
+    order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip)."""
+    (w1, b1, s1, t1), (w2, b2, s2, t2), (w3, b3, s3, t3) = layers
+    dd = lambda v, n, fill: (torch.full((n,), fill, dtype=torch.float64) if v is None else v.detach().double().cpu())
+    w1, w2, w3 = w1.detach().double().cpu(), w2.detach().double().cpu(), w3.detach().double().cpu()
+    out_c = w3.shape[0]
+    assert w1.shape == (256, 128) and w2.shape == (256, 256) and w3.shape[1] == 256 and 1 <= out_c <= 4
+    b2f = (dd(b2, 256, 0.0) + w2 @ dd(t1, 256, 0.0)).float()
+    w2 = (w2 * dd(s1, 256, 1.0)[None, :]).float()
+    b3f = (dd(b3, out_c, 0.0) + w3 @ dd(t2, 256, 0.0)).float()
+    w3 = (w3 * dd(s2, 256, 1.0)[None, :]).float()
+    w1, b1f = w1.float(), dd(b1, 256, 0.0).float()
+    sc1, sc2 = _pow2_scale(w1), _pow2_scale(w2)
+    ar = torch.arange
+    bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(2), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
+    a1 = (w1 * sc1)[32 * (2 * bp + blk) + r, 16 * (4 * kq + kg) + 8 * h + i]                     # [bp][kq][kg][blk][h][r][i]
+    bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(4), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
+    g2 = 4 * kq + kg
+    q = 8 * (g2 & 1) + i
+    a2 = (w2 * sc2)[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]
+
+    def planes(a):                                                                                # -> [stage][kg][blk][plane][h][r][i]
+        p1 = a.to(torch.float16)
+        p2 = (a - p1.float()).to(torch.float16)
+        st = torch.stack((p1, p2), dim=4)                                                         # [bp][kq][kg][blk][plane][h][r][i]
+        return st.reshape(-1, 4, 2, 2, 2, 32, 8)
+
+    wpack = torch.cat((planes(a1), planes(a2)), dim=0).contiguous().view(torch.int16)             # [24][...]
+    assert wpack.numel() * 2 == 24 * 16384
+    nb, hh, qq = torch.meshgrid(ar(8), ar(2), ar(16), indexing="ij")
+    u = 32 * nb + (qq & 3) + 8 * (qq >> 2) + 4 * hh                                               # [8][2][16]
+    tab1 = b1f[u]
+    tab2 = torch.stack([b2f[u]] + [w3[o][u] for o in range(out_c)], dim=2)                        # [8][2][1+OUT][16]
+    tail = torch.stack((b3f, dd(s3, out_c, 1.0).float(), dd(t3, out_c, 0.0).float()))
+    tab = torch.cat((tab1.reshape(-1), tab2.reshape(-1), tail.reshape(-1))).float().contiguous()
+    return DecodeSplitPack(wpack, tab, 1.0 / sc1, 1.0 / sc2, out_c)
+
+
+def implicit_decode_split(xin, pack, out=None):
+    """pre-sampled rows xin [M][128] -> out [M][OUT] through the [128,256,256,OUT] decoder on the 16-bit matrix cores"""
+    M, C0 = xin.shape
+    if out is None:
+        out = torch.empty((M, pack.out_channels), dtype=torch.float32, device=xin.device)
+    _lib.call("gn_implicit_decode_split", _p(xin), rows_view(xin)[1], int(M), _p(pack.wpack), _p(pack.tab), pack.inv1, pack.inv2,
+              C0, 256, 256, pack.out_channels, _p(out), rows_view(out)[1], _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ isosurface
 def ggm3d(vol, sigma):
     _chk(vol, torch.float32, "vol")

@@ -216,6 +216,15 @@ int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vo
  * surface decoder (mc_verts.astype(np.float32)). */
 int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *verts_out, void *stream);
 
+/* The decoder MLP of gn_implicit_decode for the shipped shape [128, 256, 256, OUT<=4] on the 16-bit matrix cores: fp32 operands
+ * split into two fp16 planes (3 MFMA products per fp32 product, fp32 accumulation -- the f16x2 arithmetic of
+ * gn_conv3d_gcr_split), activations chained through registers, weights streamed through an LDS ring
+ * (csrc/decode_split.hip).  xin: pre-sampled rows [M][ldxin] (gn_trilinear_sample); wpack / tab: weight stages and epilogue
+ * tables from garmentnets_amd.ops.pack_decode_split; inv1 / inv2: the exact powers of two undoing the weight scales.
+ * replaces the three Linear/ReLU/BatchNorm1d blocks of ImplicitWNFDecoder.forward -- networks/conv_implicit_wnf.py:128-149. */
+int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, float inv1, float inv2,
+                             int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Widening: evaluation helpers.
  * ------------------------------------------------------------------------------------------------------- */

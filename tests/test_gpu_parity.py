@@ -399,9 +399,17 @@ def test_trilinear_against_grid_sample():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.fixture(params=["f16x2", "fp32"])
+def decode_mode(request):
+    saved, ops.DECODE_MODE = ops.DECODE_MODE, request.param
+    yield request.param
+    ops.DECODE_MODE = saved
+
+
 @pytest.mark.parametrize("out_ch,M", [(1, 1000), (3, 37), (1, 32), (3, 1)])
-def test_fused_decoder_against_torch_and_unfused(out_ch, M):
-    """gn_implicit_decode (sample + 3-layer MLP in LDS) vs F.grid_sample + the oracle MLP, and vs the per-layer path."""
+def test_fused_decoder_against_torch_and_unfused(out_ch, M, decode_mode):
+    """gn_implicit_decode_split / gn_implicit_decode (3-layer MLP in one kernel, either arithmetic) vs F.grid_sample + the oracle
+    MLP, and vs the per-layer path."""
     from garmentnets_amd.networks.conv_implicit_wnf import ImplicitWNFDecoder
     g = torch.Generator().manual_seed(out_ch * 100 + M)
     dec = ImplicitWNFDecoder((128, 256, 256, out_ch), batch_norm=True)
@@ -422,6 +430,36 @@ def test_fused_decoder_against_torch_and_unfused(out_ch, M):
     gp = P.grid_points(9).reshape(1, -1, 3).repeat(2, 1, 1)
     ref_lat = P.implicit_decoder({"d." + k: v for k, v in sd.items()}, "d", vol, gp)
     np.testing.assert_allclose(lat.reshape(2, -1, out_ch).cpu().numpy(), ref_lat.numpy(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("out_ch,M,bn", [(1, 70001, True), (3, 4100, True), (2, 129, False), (4, 128, True)])
+def test_decoder_split_against_fp64(out_ch, M, bn):
+    """gn_implicit_decode_split (two fp16 planes per operand on the matrix cores, activations chained through registers, persistent
+    workgroups) against an fp64 evaluation and against the fp32-MFMA kernel on the same rows: at least as accurate."""
+    g = torch.Generator().manual_seed(out_ch * 7 + M)
+    dims = [128, 256, 256, out_ch]
+    raw, ref = [], None
+    x = torch.randn(M, 128, generator=g) * 2.0
+    x[0] = 0.0
+    h = x.double()
+    for i in range(3):
+        w = torch.randn(dims[i + 1], dims[i], generator=g) * (2.0 / dims[i]) ** 0.5 * (0.3 if i == 1 else 1.0)
+        b = torch.randn(dims[i + 1], generator=g) * 0.1
+        sc = (torch.rand(dims[i + 1], generator=g) + 0.5) if bn else None
+        sh = torch.randn(dims[i + 1], generator=g) * 0.1 if bn else None
+        raw.append((w, b, sc, sh))
+        h = torch.relu(h @ w.double().t() + b.double())
+        if bn:
+            h = h * sc.double() + sh.double()
+    xin = ops.new_rows(M, 128, DEV)
+    xin.copy_(x.to(DEV))
+    out = ops.implicit_decode_split(xin, ops.pack_decode_split(raw).to(DEV))
+    dv = lambda t: None if t is None else t.to(DEV)
+    layers = tuple((ops.pack_kpair(w).to(DEV) if i < 2 else w.contiguous().to(DEV), b.to(DEV), dv(sc), dv(sh), dims[i + 1]) for i, (w, b, sc, sh) in enumerate(raw))
+    out32 = ops.implicit_decode(None, layers, M=M, xin=xin)
+    e_split, e_f32 = (out.cpu().double() - h).abs().max().item(), (out32.cpu().double() - h).abs().max().item()
+    print(f"decoder [128,256,256,{out_ch}] M={M}: err vs fp64 split {e_split:.2e}, fp32-MFMA {e_f32:.2e}, |y| max {h.abs().max():.2f}")
+    assert e_split <= max(2 * e_f32, 2e-6) and e_split <= 2e-5
 
 
 # ------------------------------------------------------------------------------------------------ isosurface
