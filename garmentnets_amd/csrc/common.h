@@ -49,4 +49,14 @@ __device__ __forceinline__ float gn_sqdist3(float ax, float ay, float az, float 
     return s;
 }
 
+// 16 bytes per lane global -> LDS DMA (wave-uniform LDS destination `lds_addr` + 16 * lane), issued from inline asm ON PURPOSE:
+// hipcc (ROCm 7.2) guards every ds_read that follows a __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0) (it cannot prove
+// the read does not alias the DMA's destination), which drains a multi-stage ring at every step.  Users make slot reuse safe by
+// hand (counted s_waitcnt vmcnt(N) + s_barrier) and must not use m0 otherwise.
+__device__ __forceinline__ void gn_glds16(const void *g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+// s_waitcnt vmcnt(N) lgkmcnt(0)   (gfx9 immediate: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt_hi[15:14])
+#define GN_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
+
 __device__ __forceinline__ int gn_lane() { return threadIdx.x & 63; }

@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x16q ds_mfma(const uint4 &a, const uint4 &b, const
 // counted s_waitcnt + s_barrier of the stage hand-over.  Measured (262144 rows): 0.165 ms with the asm DMA, 0.201 ms with the
 // builtin, 0.545 ms for the fp32-MFMA kernel.  (m0 = LDS byte address of the wave's 1-KB destination; lane i lands at
 // +16 i.  Nothing else in this kernel uses m0.)
-__device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {
+__device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {  // = gn_glds16 (common.h)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
 }
 

@@ -28,13 +28,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SP_HX (SP_TX + 2)
 #define SP_HVOX (SP_HZ * SP_HY * SP_HX)
 #define SP_KS 16
+#ifndef SP_ABL
+#define SP_ABL 0     // dev-only ablation switches (tools/dev/ab_split_abl.py); 0 in the product build
+#endif
 
 struct SplitArgs {
     const float *src0;
     const float *src1;
     const float *a;
     const float *d;
-    const uint4 *wp;   // [slice][tap][Cout/32][P][lane 64] x 16 B (8 bf16: channels 8h..8h+7 of cout 32*blk + r, lane = 32h + r), + two zero pad steps
+    const uint4 *wp;   // [slice][tap][Cout/32][P][lane 64] x 16 B (8 bf16: channels 8h..8h+7 of cout 32*blk + r, lane = 32h + r), + four zero pad steps
     float *out;
     double *osum;
     double *osq;
@@ -88,12 +91,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     constexpr int CT = NT * 32;
     // LDS (ONE array: a second __shared__ object makes hipcc drain the LDS-DMA queue before every ds_read):
     //   halo : 600 voxels x VB bytes, VB = P planes of 16 bf16 + one 16-byte pad slot (odd slot stride: voxels rotate over the banks)
-    //   ring : 2 x (NT*P) B fragments of 1 KB in lane order, filled by global_load_lds_dwordx4 two taps ahead
+    //   ring : DEPTH x (NT*P) B fragments of 1 KB in lane order, filled by global_load_lds_dwordx4 DEPTH taps ahead
     constexpr int VB = P * 32 + 16;
     constexpr int HALO_BYTES = SP_HVOX * VB;
     constexpr int BTAP = NT * P * 1024;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[HALO_BYTES + 2 * BTAP];
+    constexpr int DEPTH = (P == 2) ? 4 : 2;         // power of two; P = 3 has no LDS to spare next to its 67 KB halo
+    constexpr int CH = (NT * P + 3) / 4;            // DMA instructions per wave per tap (the same for every wave: counted waits)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HALO_BYTES + DEPTH * BTAP];
     unsigned char *const halo = smem;
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C0 + p.C1;
@@ -126,22 +132,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     constexpr int AF1 = 4 * SP_HX * VB;
     const int nslices = Cin / SP_KS;
     // B operands: the pack is in fragment order [slice][tap][Cout/32][plane][lane] (16 B per lane), so the NT*P fragments a
-    // workgroup needs for one (slice, tap) step are NT*P contiguous KB.  They are DMA'd into the ring (global_load_lds: no
-    // VGPRs, one wave per 1-KB fragment, round robin) two steps ahead and read back in lane order (conflict-free b128).
+    // workgroup needs for one (slice, tap) step are NT*P contiguous KB.  They are DMA'd into the ring DEPTH steps ahead (no VGPRs;
+    // every wave issues CH 1-KB pieces per step -- when NT*P is not a multiple of 4 some pieces are fetched twice, harmlessly, so
+    // that the s_waitcnt counts are the same in every wave) and read back in lane order (conflict-free b128).
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;                          // bytes per (slice, tap) step
     const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + lane * 16;
-#define SP_ISSUE_B(SLOT_OFF, ROT)                                                                                              \
-    _Pragma("unroll") for (int c = 0; c < NT * P; ++c)                                                                         \
-        if (((c + (ROT)) & 3) == wave)                                                                                         \
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bg + c * 1024), reinterpret_cast<unsigned *>(smem + HALO_BYTES + (SLOT_OFF) + c * 1024), 16, 0, 0);
-    SP_ISSUE_B(0, 0)
-    bg += bstep;
-    SP_ISSUE_B(BTAP, 1)
-    bg += bstep;                                   // bg -> step j + 2 from here on
+    int jf = 0;                                     // flat step index s*27 + tap of the NEXT step to fetch
+#define SP_ISSUE_B()                                                                                                           \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                       \
+            const int c = (wave + 4 * k) % (NT * P);                                                                           \
+            gn_glds16(bg + c * 1024, lds_ring + (jf & (DEPTH - 1)) * BTAP + c * 1024);                                         \
+        }                                                                                                                      \
+        bg += bstep; ++jf;                                                                                                     \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) SP_ISSUE_B();
 
     for (int s = 0; s < nslices; ++s) {
         const int c0 = s * SP_KS;
         // (every halo read of the previous slice completed before its last tap's barrier: the halo can be overwritten)
+        if (!(SP_ABL & 2) || s == 0)
         {   // ---- halo stage: GroupNorm affine, then exact split into P bf16 planes.  All the tile's loads are issued before the
             //      first use (one exposed latency per slice), the other workgroup of the CU computes meanwhile
             const bool from1 = c0 >= p.C0;
@@ -191,9 +202,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             }
         }
         __syncthreads();                            // halo visible (and this wave's outstanding ring DMAs have landed)
-        // ring slot of step j = s*27 + tap is j & 1 = (s & 1) ^ (tap & 1)   (27 is odd)
-        const int slot_e = (s & 1) * BTAP, slot_o = BTAP - slot_e;         // byte offsets of the slots of even / odd taps
+        // step j = s*27 + tap lives in ring slot j % DEPTH
         const unsigned char *const ring_rd = smem + HALO_BYTES + lane * 16;
+        int jcur = s * 27;
         uint4 a0[P], a1[P], na0[P], na1[P], bf[NT][P], nbf[NT][P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
@@ -203,19 +214,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + slot_e + (u * P + i) * 1024);
+            for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (jcur & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
 #pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            const int slot_cur = (tap & 1) ? slot_o : slot_e, slot_nxt = (tap & 1) ? slot_e : slot_o;
+        for (int tap = 0; tap < 27; ++tap, ++jcur) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
 #pragma unroll
             for (int u = 0; u < NT; ++u)
 #pragma unroll
                 for (int i = 0; i < P; ++i) bf[u][i] = nbf[u][i];
-            // every wave holds step j's fragments in registers and its DMA share of step j+1 has landed
-            __syncthreads();
-            if (tap + 1 < 27) {
+            // hand-over: every wave holds step j's fragments in registers (lgkmcnt(0)) and its DMA share of step j+1 has landed
+            // (VM queue, oldest first: steps j+1 .. j+DEPTH-1, CH pieces each)
+            if (!(SP_ABL & 8)) {
+                GN_WAIT_VM_LGKM0((DEPTH - 2) * CH);
+                __builtin_amdgcn_s_barrier();
+            }
+            if (tap + 1 < 27 && !(SP_ABL & 4)) {
                 const int t1 = tap + 1;
                 const int toff = (((t1 / 9) * SP_HY + (t1 / 3) % 3) * SP_HX + t1 % 3) * VB;
 #pragma unroll
@@ -226,10 +240,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
 #pragma unroll
-                    for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + slot_nxt + (u * P + i) * 1024);
+                    for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
             }
-            SP_ISSUE_B(slot_cur, tap)               // step j+2 overwrites step j's slot (read by everyone before the barrier)
-            bg += bstep;
+            if (!(SP_ABL & 1)) SP_ISSUE_B();        // step j+DEPTH overwrites step j's slot (read by everyone before the barrier)
             __builtin_amdgcn_sched_barrier(0);
 #define SP_PROD(IA, IB)                                                                                                        \
             _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
@@ -252,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
     }
 #undef SP_ISSUE_B
-    __syncthreads();                                // drains the two pad-step DMAs; the epilogue reuses the halo as scratch
+    GN_WAIT_VM_LGKM0(0);                            // the pad-step DMAs must land before the LDS goes away
+    __syncthreads();                                // the epilogue reuses the halo as scratch
     // ---- epilogue (identical to the fp32 kernel)
     const int gz = z0 + wave;
     float ssum[NT], ssq[NT];

@@ -232,8 +232,8 @@ class SplitPack:
 
 def pack_conv_weight_split(w, mode):
     """(Cout, Cin, 3,3,3) fp32 -> exact plane decomposition (w = w1 + w2 [+ w3], residual chain) in MFMA-fragment order
-    [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by two zero
-    (slice, tap) steps: the kernel's fragment DMA runs two steps ahead.  mode SPLIT_BF16X2/3: bf16 planes;
+    [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by four zero
+    (slice, tap) steps: the kernel's fragment DMA runs up to four steps ahead.  mode SPLIT_BF16X2/3: bf16 planes;
     SPLIT_F16X2: two fp16 planes of w * 2^k, k chosen so that max|w| * 2^k is in [1, 2) (out_scale = 2^-k undoes it exactly)."""
     if mode not in (SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2):
         raise ValueError(f"unknown split mode {mode}")
@@ -253,7 +253,7 @@ def pack_conv_weight_split(w, mode):
         r = r - p.float()
     pk = torch.stack(out, dim=3).contiguous()                                                            # [S][tap][blk][planes][h][r][8]
     pk = pk.reshape(cin // 16 * 27, -1)
-    pk = torch.cat([pk, torch.zeros_like(pk[:2])], dim=0)
+    pk = torch.cat([pk, torch.zeros_like(pk[:4])], dim=0)
     return SplitPack(pk.contiguous().view(torch.int16), mode, 1.0 / scale)
 
 

@@ -150,7 +150,7 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
  *   GN_SPLIT_BF16X3: 3 bf16 planes, 6 partial products, dropped terms <= 2^-24 relative (fp32-class products)
  *   GN_SPLIT_F16X2 : 2 fp16 planes, 3 partial products, operand residual and dropped term <= 2^-22 relative
  *   GN_SPLIT_BF16X2: 2 bf16 planes, 3 partial products, 2^-16 relative (fast preview quality)
- * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + two zero steps
+ * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + four zero steps
  * (garmentnets_amd.ops.pack_conv_weight_split); out_scale: the exact power of two that undoes the pack's weight scale
  * (fp16 mode; 1 for bf16). */
 #define GN_SPLIT_BF16X2 2
