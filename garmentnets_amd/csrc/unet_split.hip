@@ -307,6 +307,224 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 128-wide variant (P = 2)
+// For Cout % 128 == 0 (58 % of the UNet's FLOPs: the 128 -> 128 layers at full resolution).  512 threads = 8 waves: wave =
+// (z-slice zs, column group cg), the two column groups share ONE halo, so the GroupNorm-affine + plane-split staging is done once
+// per 128 output channels instead of once per 64.  The halo is DOUBLE-buffered (2 x 48 KB + 32 KB ring = 126 KB, one workgroup
+// per CU = 2 waves per SIMD as before): slice s+1 is staged WHILE slice s is multiplied -- its 5 row loads per thread are issued at
+// tap 0 (inline asm, so that hipcc's own vmcnt bookkeeping does not drain the fragment DMAs) and converted / written one per tap
+// at taps 8-12, ordered by the per-tap barriers alone.  The matrix-core stream never stops for staging.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <int P, bool F16>
+__global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
+    static_assert(P == 2, "the wide variant is sized for the two-plane modes");
+    constexpr int NT = 2;
+    constexpr int VB = P * 32 + 16;
+    constexpr int HALO_BYTES = SP_HVOX * VB;
+    constexpr int BTAP = 2 * NT * P * 1024;         // both column groups
+    constexpr int DEPTH = 4, CH = 1;                // 8 one-KB pieces per step, one per wave
+    constexpr int NIT = (SP_HVOX * 4 + 511) / 512;  // 5 row loads per thread per slice
+    constexpr int AD_OFF = 2 * HALO_BYTES + DEPTH * BTAP;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[AD_OFF + 2 * 384 * 4];
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + 2 * HALO_BYTES;
+    float *const adl = reinterpret_cast<float *>(smem + AD_OFF);          // a[Cin] | d[Cin] of this sample
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), zs = wave & 3, cg = wave >> 2;
+    const int Cin = p.C0 + p.C1;
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
+    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
+    const int ncb = p.Cout / 128;
+    int tile = (int)(logical / (unsigned)ncb);
+    const int cb = (int)(logical % (unsigned)ncb);
+    const int tiles_z = (p.D + 3) / 4;
+    const int tz = tile % tiles_z; tile /= tiles_z;
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile;
+    const int z0 = tz * SP_TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
+    const int n0 = cb * 128 + cg * 64;
+    const int b = blockIdx.y;
+    const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
+    const int nslices = Cin / SP_KS;
+
+    f32x16s acc[2][NT], tot[2][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
+
+    for (int i = tid; i < Cin; i += 512) { adl[i] = p.a[(int64_t)b * Cin + i]; adl[384 + i] = p.d[(int64_t)b * Cin + i]; }
+
+    const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
+    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + wave * 1024 + lane * 16;
+    int jf = 0;
+#define SPW_ISSUE_B()                                                                                                          \
+    do {                                                                                                                       \
+        gn_glds16(bg, lds_ring + (jf & (DEPTH - 1)) * BTAP + wave * 1024);                                                     \
+        bg += bstep; ++jf;                                                                                                     \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i) SPW_ISSUE_B();   // step j+DEPTH-1 is issued at tap j, after its barrier
+
+    // ---- staging of one 16-channel slice, split in two halves that can be far apart in time
+    const int c4 = (tid & 3) * 4;                   // 512 % 4 == 0: the same channel quad every iteration
+    f32x4w raw[NIT];
+    unsigned inb = 0;                               // bit it: the voxel of iteration it lies inside the volume
+    auto issue_rows = [&](int sl) {
+        const int c0 = sl * SP_KS;
+        const bool from1 = c0 >= p.C0;
+        const float *src = from1 ? p.src1 : p.src0;
+        const int Cs = from1 ? p.C1 : p.C0;
+        const int cs = from1 ? c0 - p.C0 : c0;
+        inb = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 512;
+            const int hv = (idx < SP_HVOX * 4 ? idx : SP_HVOX * 4 - 1) >> 2;
+            const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool in = idx < SP_HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            int64_t off = (int64_t)b * (from1 ? (int64_t)D1 * H1 * W1 : (int64_t)p.D * p.H * p.W) * Cs;   // a valid address when outside
+            if (in) {
+                if (from1) off = ((((int64_t)b * D1 + (gz >> 1)) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * Cs + cs + c4;
+                else off = ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * Cs + cs + c4;
+                inb |= 1u << it;
+            }
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[it]) : "v"(src + off) : "memory");
+        }
+    };
+    auto convert_row = [&](int it, int sl, int buf) {
+        const int idx = tid + it * 512;
+        asm volatile("" : "+v"(raw[it]));           // the loads above are invisible to hipcc's waitcnt pass: pin the first use here
+        if (idx < SP_HVOX * 4) {
+            const int hv = idx >> 2;
+            const float4 av = *reinterpret_cast<const float4 *>(adl + sl * SP_KS + c4);
+            const float4 dv = *reinterpret_cast<const float4 *>(adl + 384 + sl * SP_KS + c4);
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (inb & (1u << it)) {                  // zero padding comes AFTER the affine
+                v0 = __fadd_rn(__fmul_rn(raw[it].x, av.x), dv.x);
+                v1 = __fadd_rn(__fmul_rn(raw[it].y, av.y), dv.y);
+                v2 = __fadd_rn(__fmul_rn(raw[it].z, av.z), dv.z);
+                v3 = __fadd_rn(__fmul_rn(raw[it].w, av.w), dv.w);
+            }
+            uint2 pl[P];
+            split4<P, F16>(v0, v1, v2, v3, pl);
+#pragma unroll
+            for (int i = 0; i < P; ++i) *reinterpret_cast<uint2 *>(smem + buf * HALO_BYTES + hv * VB + i * 32 + c4 * 2) = pl[i];
+        }
+    };
+
+    // slice 0 synchronously
+    issue_rows(0);
+    GN_WAIT_VM_LGKM0(0);
+    __syncthreads();                                // a / d table visible
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) convert_row(it, 0, 0);
+    __syncthreads();
+
+    const int abase = ((zs * SP_HY + (r >> 3)) * SP_HX + (r & 7)) * VB + 16 * h;
+    constexpr int AF1 = 4 * SP_HX * VB;
+    const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (cg * NT * P) * 1024 + lane * 16;
+    int jcur = 0;
+    for (int s = 0; s < nslices; ++s) {
+        const unsigned char *const halo = smem + (s & 1) * HALO_BYTES;
+        const int sn = s + 1 < nslices ? s + 1 : s;
+        uint4 a0[P], a1[P], na0[P], na1[P], bf[NT][P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + i * 32);
+            na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + i * 32);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap, ++jcur) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
+            // hand-over: step j's fragments have landed for everybody and everybody is done with step j-1's slot.  VM queue,
+            // oldest first: fragment steps j .. j+DEPTH-2 and, for taps 1-3, the NIT row loads issued at tap 0 (younger than the
+            // DMA of tap 0, older than the DMA of tap 1): they may still be in flight there
+            if (tap >= 1 && tap <= 3) GN_WAIT_VM_LGKM0((DEPTH - 2) * CH + NIT); else GN_WAIT_VM_LGKM0((DEPTH - 2) * CH);
+            __builtin_amdgcn_s_barrier();
+            SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 just vacated
+            // B fragments are read straight after the barrier (no register double buffer: 16 VGPRs the kernel does not have)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (jcur & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
+            if (tap + 1 < 27) {
+                const int t1 = tap + 1;
+                const int toff = (((t1 / 9) * SP_HY + (t1 / 3) % 3) * SP_HX + t1 % 3) * VB;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + toff + i * 32);
+                    na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + toff + i * 32);
+                }
+            }
+            if (tap == 0) issue_rows(sn);                                        // always (uniform wait counts); unused after the last slice
+            __builtin_amdgcn_sched_barrier(0);
+#define SPW_PROD(IA, IB)                                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
+                acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                         \
+                acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                         \
+            }
+            SPW_PROD(1, 0)
+            if (tap >= 8 && tap < 8 + NIT && s + 1 < nslices) convert_row(tap - 8, sn, (s + 1) & 1);
+            SPW_PROD(0, 1) SPW_PROD(0, 0)
+#undef SPW_PROD
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
+    }
+#undef SPW_ISSUE_B
+    GN_WAIT_VM_LGKM0(0);
+    __syncthreads();                                // pad-step DMAs landed; the epilogue reuses the halo as scratch
+    const int gz = z0 + zs;
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int n = n0 + u * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
+                if (gz < p.D && gy < p.H && gx < p.W) {
+                    float v = __fmul_rn(tot[t][u][q], p.out_scale);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
+                    ssum[u] += v;
+                    ssq[u] = fmaf(v, v, ssq[u]);
+                }
+            }
+        }
+    if (p.osum) {
+        float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][cg][zs][64]
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
+            if (h == 0) { red[(cg * 4 + zs) * 64 + u * 32 + r] = s2; red[512 + (cg * 4 + zs) * 64 + u * 32 + r] = q2; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int g = tid >> 6, c = tid & 63;
+            const float *rs = red + g * 256 + c, *rq = red + 512 + g * 256 + c;
+            const double s4 = (double)rs[0] + (double)rs[64] + (double)rs[128] + (double)rs[192];
+            const double q4 = (double)rq[0] + (double)rq[64] + (double)rq[128] + (double)rq[192];
+            atomicAdd(&p.osum[(int64_t)b * p.Cout + cb * 128 + tid], s4);
+            atomicAdd(&p.osq[(int64_t)b * p.Cout + cb * 128 + tid], q4);
+        }
+    }
+}
+
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, float out_scale, int B, int D, int H, int W, int Cout, int relu,
                                    float *out, double *out_sum, double *out_sumsq, void *stream) {
@@ -329,12 +547,19 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
+    const int Cin_total = C0 + C1;
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
 #define SP_LAUNCH(P_, F16_)                                                                                                    \
     do {                                                                                                                       \
         if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, P_, F16_>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);   \
         else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);        \
     } while (0)
+    // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
+    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && (int64_t)tiles * (Cout / 128) * B >= 512;
+    if (wide128) {
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+    } else
     if (mode == GN_SPLIT_BF16X3) SP_LAUNCH(3, false);
     else if (mode == GN_SPLIT_BF16X2) SP_LAUNCH(2, false);
     else SP_LAUNCH(2, true);
