@@ -68,6 +68,8 @@ class ConvTimer:
                 cin = C0 + (0 if src1 is None else src1.shape[-1])
                 tiles = -(-D // 4) * -(-H // 8) * -(-W // 8)
                 nt = 2 if (cout % 64 == 0 and tiles * (cout // 64) * B >= 1024) else 1
+                if hasattr(wp, "mode") and wp.mode != 3 and cout % 128 == 0 and cin <= 384 and tiles * (cout // 128) * B >= 512:
+                    nt = 4                                  # the 128-wide variant (same dispatch rule as gn_conv3d_gcr_split)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = orig(src0, src1, a, d, wp, cout, relu, with_stats)
@@ -78,8 +80,8 @@ class ConvTimer:
             return timed
 
         ops.conv3d_gcr = wrap(ops.conv3d_gcr, lambda nt, wp: f"conv3d_gcr_kernel<{nt}>")
-        ops.conv3d_gcr_split = wrap(ops.conv3d_gcr_split, lambda nt, wp: "conv3d_split_kernel<%d, %d, %s>" % (
-            nt, 3 if wp.mode == ops.SPLIT_BF16X3 else 2, "true" if wp.mode == ops.SPLIT_F16X2 else "false"))
+        ops.conv3d_gcr_split = wrap(ops.conv3d_gcr_split, lambda nt, wp: ("conv3d_split_wide_kernel<2, %s>" if nt == 4 else "conv3d_split_kernel<%d, %d, %%s>" % (
+            nt, 3 if wp.mode == ops.SPLIT_BF16X3 else 2)) % ("true" if wp.mode == ops.SPLIT_F16X2 else "false"))
         import garmentnets_amd.components.unet3d as u
         u.ops = ops
 

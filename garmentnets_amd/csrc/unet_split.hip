@@ -1,4 +1,5 @@
-// unet_split.hip -- OPT-IN split-precision variant of the 'gcr' conv (gn_conv3d_gcr_split), NOT the default path.
+// unet_split.hip -- split-operand variant of the 'gcr' conv on the 16-bit matrix cores (gn_conv3d_gcr_split).  Its f16x2 mode is
+// the default conv arithmetic of garmentnets_amd (ops.CONV_MODE); unet.hip holds the plain fp32-MFMA kernel.
 //
 // Same implicit-GEMM structure, tiling, GroupNorm-on-load, upsample/concat folding and epilogue as conv3d_gcr_kernel
 // (unet.hip), but every fp32 operand is decomposed EXACTLY into P bf16 planes (x = x1 + x2 [+ x3], xi = bf16_rn of the

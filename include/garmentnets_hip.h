@@ -144,7 +144,8 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
                   const float *wp, int B, int D, int H, int W, int Cout, int relu, float *out, double *out_sum,
                   double *out_sumsq, void *stream);
 
-/* OPT-IN split-precision variant of gn_conv3d_gcr (never used unless the host asks for it): identical contract, but the
+/* Split-operand variant of gn_conv3d_gcr on the 16-bit matrix cores (GN_SPLIT_F16X2 is what garmentnets_amd uses by default;
+ * gn_conv3d_gcr is the plain fp32-MFMA kernel): identical contract, but the
  * fp32 operands are decomposed into low-precision planes (x = x1 + x2 [+ x3], exact residual chain) and multiplied on the
  * 16-bit matrix cores with fp32 accumulation:
  *   GN_SPLIT_BF16X3: 3 bf16 planes, 6 partial products, dropped terms <= 2^-24 relative (fp32-class products)
