@@ -91,9 +91,12 @@ class ImplicitWNFDecoder(PackedModule):
     def _decode_rows(self, vol_b, out, query=None, Q=0):
         M = out.shape[0]
         layers = self.packed() if self.fused else None
-        buf = ops.new_rows(min(M, self.ROWS_PER_CHUNK), vol_b.shape[-1], vol_b.device)
-        for m0 in range(0, M, self.ROWS_PER_CHUNK):
-            m = min(self.ROWS_PER_CHUNK, M - m0)
+        chunk = self.ROWS_PER_CHUNK
+        if query is None:                           # lattice: whole i-slabs per chunk (the brick sampler's unit)
+            chunk = max(1, chunk // (Q * Q)) * Q * Q
+        buf = ops.new_rows(min(M, chunk), vol_b.shape[-1], vol_b.device)
+        for m0 in range(0, M, chunk):
+            m = min(chunk, M - m0)
             if query is not None:
                 s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m], out=buf[:m])
             else:

@@ -399,6 +399,23 @@ def test_trilinear_against_grid_sample():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dims,Q,C", [((8, 8, 8), 8, 32), ((6, 5, 7), 9, 128), ((16, 16, 16), 21, 64), ((32, 32, 32), 32, 128), ((5, 9, 3), 12, 32)])
+def test_lattice_brick_sampler_is_bit_identical(dims, Q, C):
+    """gn_trilinear_sample on whole lattice slabs (brick kernel: voxel bounding box staged in LDS) == the per-query kernel,
+    bit for bit (forced by a chunk that does not start on a slab), and == F.grid_sample within rounding."""
+    D, H, W = dims
+    vol = torch.randn(D, H, W, C, generator=torch.Generator().manual_seed(Q + C)).to(DEV)
+    n = Q * Q * Q
+    brick = ops.trilinear_sample(vol, Q=Q, m0=0, M=n)
+    per_query = ops.trilinear_sample(vol, Q=Q, m0=1, M=n - 1)
+    assert torch.equal(brick[1:], per_query)
+    part = ops.trilinear_sample(vol, Q=Q, m0=2 * Q * Q, M=3 * Q * Q)          # a chunk of slabs 2..4
+    assert torch.equal(part, brick[2 * Q * Q:5 * Q * Q])
+    gp = P.grid_points(Q).reshape(1, -1, 1, 1, 3)
+    ref = F.grid_sample(vol.cpu().permute(3, 0, 1, 2)[None], 2.0 * gp - 1.0, mode="bilinear", padding_mode="border", align_corners=True)
+    np.testing.assert_allclose(brick.cpu().numpy(), ref.view(C, -1).t().numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.fixture(params=["f16x2", "fp32"])
 def decode_mode(request):
     saved, ops.DECODE_MODE = ops.DECODE_MODE, request.param
