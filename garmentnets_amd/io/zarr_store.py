@@ -43,39 +43,42 @@ class Group:
         _write_json(os.path.join(self.path, ".zattrs"), attrs)
 
     def array(self, name, data, chunks=None, compressor=None, overwrite=True):
-        """one chunk per array (chunks == data.shape), C order; compressor: None or ("zlib", level)"""
+        """C-order Zarr v2 array; chunks=None -> one chunk (chunks == data.shape: what the reference's prediction.zarr uses), else a
+        chunk grid with full-size (fill-padded) edge chunks; compressor: None or ("zlib", level)"""
         data = np.ascontiguousarray(data)
         apath = os.path.join(self.path, name)
         os.makedirs(apath, exist_ok=True)
         comp = None
-        raw = data.tobytes()
         if compressor is not None:
             cid, level = compressor
             assert cid == "zlib"
             comp = {"id": "zlib", "level": int(level)}
-            raw = zlib.compress(raw, int(level))
         shape = list(data.shape)
-        meta = {"chunks": shape if shape else [], "compressor": comp, "dtype": data.dtype.str, "fill_value": None if data.dtype.kind == "f" else 0,
+        cshape = shape if chunks is None else [int(c) for c in chunks]
+        assert len(cshape) == len(shape)
+        fill = 0.0 if data.dtype.kind == "f" else 0
+        meta = {"chunks": cshape, "compressor": comp, "dtype": data.dtype.str, "fill_value": fill,
                 "filters": None, "order": "C", "shape": shape, "zarr_format": 2}
-        if data.dtype.kind == "f":
-            meta["fill_value"] = 0.0
         _write_json(os.path.join(apath, ".zarray"), meta)
-        key = ".".join("0" for _ in shape) if shape else "0"
-        with open(os.path.join(apath, key), "wb") as f:
-            f.write(raw)
+        grid = list(np.ndindex(*[-(-n // c) for n, c in zip(shape, cshape)])) if shape else [()]
+        for ci in grid:
+            if shape:
+                block = np.full(cshape, fill, dtype=data.dtype)
+                sl = tuple(slice(i * c, min((i + 1) * c, n)) for i, c, n in zip(ci, cshape, shape))
+                block[tuple(slice(0, s.stop - s.start) for s in sl)] = data[sl]
+            else:
+                block = data
+            raw = np.ascontiguousarray(block).tobytes()
+            if comp is not None:
+                raw = zlib.compress(raw, comp["level"])
+            with open(os.path.join(apath, ".".join(str(i) for i in ci) if ci else "0"), "wb") as f:
+                f.write(raw)
 
     # -- read ----------------------------------------------------------------------------------------------
     def __getitem__(self, name):
         path = os.path.join(self.path, *name.strip("/").split("/"))
         if os.path.exists(os.path.join(path, ".zarray")):
-            meta = json.load(open(os.path.join(path, ".zarray")))
-            shape = tuple(meta["shape"])
-            key = ".".join("0" for _ in shape) if shape else "0"
-            raw = open(os.path.join(path, key), "rb").read()
-            if meta["compressor"] is not None:
-                assert meta["compressor"]["id"] == "zlib"
-                raw = zlib.decompress(raw)
-            return np.frombuffer(raw, dtype=np.dtype(meta["dtype"])).reshape(shape).copy()
+            return _read_array(path)
         if os.path.exists(os.path.join(path, ".zgroup")):
             return Group(path, create=False)
         raise KeyError(name)
@@ -89,8 +92,44 @@ class Group:
         return json.load(open(p)) if os.path.exists(p) else {}
 
 
-def open_group(path):
-    return Group(path)
+def _read_array(path):
+    """Zarr v2 array -> numpy: any chunk grid (C order, '.' or '/' chunk keys, edge chunks stored full-size, missing chunks =
+    fill_value), compressor None or zlib (Blosc needs numcodecs, which is not installable offline: reported, not guessed)."""
+    meta = json.load(open(os.path.join(path, ".zarray")))
+    shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
+    dtype = np.dtype(meta["dtype"])
+    comp = meta.get("compressor")
+    if comp is not None and comp.get("id") != "zlib":
+        raise NotImplementedError(f"{path}: compressor {comp.get('id')!r} needs numcodecs (only zlib / uncompressed chunks are readable here)")
+    if meta.get("filters"):
+        raise NotImplementedError(f"{path}: filters are not supported")
+    if meta.get("order", "C") != "C":
+        raise NotImplementedError(f"{path}: only C-order chunks are supported")
+    sep = meta.get("dimension_separator", ".")
+    fill = meta.get("fill_value")
+    out = np.full(shape, 0 if fill is None else fill, dtype=dtype)
+    if not shape:
+        grid = [()]
+    else:
+        grid = list(np.ndindex(*[-(-n // c) for n, c in zip(shape, chunks)]))
+    for ci in grid:
+        f = os.path.join(path, sep.join(str(i) for i in ci) if ci else "0")
+        if not os.path.exists(f):
+            continue
+        raw = open(f, "rb").read()
+        if comp is not None:
+            raw = zlib.decompress(raw)
+        block = np.frombuffer(raw, dtype=dtype).reshape(chunks if shape else ())
+        if not shape:
+            out[...] = block
+            continue
+        sl = tuple(slice(i * c, min((i + 1) * c, n)) for i, c, n in zip(ci, chunks, shape))
+        out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+    return out
+
+
+def open_group(path, create=True):
+    return Group(path, create=create)
 
 
 def write_sample(samples_group, key, mesh, point_cloud, misc, attrs=None, compressor=("zlib", 1)):

@@ -117,6 +117,9 @@ def main(argv=None):
     ap.add_argument("--reduce_method", default="max")
     ap.add_argument("--out", default=None, help="optional .npz with the last mesh")
     ap.add_argument("--zarr_out", default=None, help="optional prediction.zarr directory (reference group layout, Zarr v2)")
+    ap.add_argument("--zarr_in", default=None, help="garmentnets dataset (Zarr v2, zlib / uncompressed chunks): read the clouds through "
+                                                    "io.dataset.GarmentInputDataset (num_views / static seed / no augmentation as in predict_default.yaml) instead of synthetic ones")
+    ap.add_argument("--num_views", type=int, default=4)
     a = ap.parse_args(argv)
     device = torch.device("cuda:{}".format(a.gpu_id))
     if a.checkpoint_path:
@@ -127,10 +130,18 @@ def main(argv=None):
         model.load_state_dict(synthetic.synthetic_state_dict(hp, 0))
     model = model.to(device).eval().requires_grad_(False)
     last = None
-    for i in range(a.num_samples):   # batch_size == 1 as asserted by predict.py:62
-        x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
+    dataset = None
+    if a.zarr_in:
+        from .io.dataset import GarmentInputDataset
+        dataset = GarmentInputDataset(a.zarr_in, num_pc_sample=a.num_pc_sample, num_views=a.num_views, static_epoch_seed=True, enable_augumentation=False)
+    for i in range(min(a.num_samples, len(dataset)) if dataset is not None else a.num_samples):   # batch_size == 1 as asserted by predict.py:62
+        if dataset is not None:
+            data = GarmentInputDataset.collate([dataset[i]])
+        else:
+            x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
+            data = Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch)
         t0 = time.time()
-        res = predict_batch(model, Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch).to(device), a.volume_size,
+        res = predict_batch(model, data.to(device), a.volume_size,
                             a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction)[0]
         last = to_host(res)
         if a.zarr_out:
