@@ -109,13 +109,18 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------------ lattice sampler, brick version
 // The lattice of predict.py:145-147 sampled brick by brick (TB_I x TB_J x TB_K lattice points per workgroup): when the lattice is at
 // least as fine as the volume (Q >= size: the north-star's 128^3 / 128^3, the shipped 128^3 / 32^3) neighbouring queries share
-// almost all of their 8 corners, so the brick's voxel bounding box (<= 6 x 6 x 10 voxels) of one 32-channel group is DMA'd into
+// almost all of their 8 corners, so the brick's voxel bounding box (<= 6 x 6 x 6 voxels) of one 32-channel group is DMA'd into
 // LDS (global_load_lds, 128-byte pieces) and every corner is an LDS read: L2 traffic falls from 8 x 512 B per query to
 // ~1.8 x 512 B.  Same arithmetic and accumulation order as tri_query (bit-identical output, checked in the tests).
 #define TB_I 4
 #define TB_J 4
-#define TB_K 8
+#ifndef TB_K
+#define TB_K 4
+#endif
 #define TB_Q (TB_I * TB_J * TB_K)
+#ifndef TB_ABL
+#define TB_ABL 0      // dev-only ablation switches (tools/dev/ab_sampler_abl.py)
+#endif
 
 __device__ __forceinline__ float tb_coord(int i, int Q) {
     const float sc = __fdiv_rn(1.0f, __fsub_rn((float)Q, 1.0f));
@@ -174,17 +179,15 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
     }
 
     {
-        if (in_lds) {
-            // stage [voxel][32 channels]: item = voxel * 8 + 16-byte piece; 64 consecutive items = 1 KB = one DMA instruction
-            const int nitems = nvox * 8;
-            for (int base = wave * 64; base < nitems; base += 256) {
-                int item = base + lane;
-                if (item >= nitems) item = nitems - 1;                      // the tail re-fetches the last piece (LDS padded to 4 KB)
-                const int v = item >> 3, pc = item & 7;
-                const int vx = v % ex, vy = (v / ex) % ey, vz = v / (ex * ey);
-                const float *g = vol + ((((int64_t)(lz + vz) * H + (ly + vy)) * W + (lx + vx)) * C + cg * 32 + pc * 4);
-                gn_glds16(g, lds_base + base * 16);
-            }
+        if (in_lds && !(TB_ABL & 1)) {
+            // stage [voxel][32 channels]: one DMA instruction per (z, y) row of the box = ex voxels x 8 16-byte pieces, lane = voxel * 8 +
+            // piece (<= 48 active lanes; no integer divisions: waves take whole z planes)
+            const int vx = lane >> 3, pc = lane & 7;
+            for (int vz = wave; vz < ez; vz += 4)
+                for (int vy = 0; vy < ey; ++vy) {
+                    const float *g = vol + ((((int64_t)(lz + vz) * H + (ly + vy)) * W + (lx + vx)) * C + cg * 32 + pc * 4);
+                    if (vx < ex) gn_glds16(g, lds_base + ((vz * ey + vy) * ex) * 128);
+                }
             GN_WAIT_VM_LGKM0(0);
             __syncthreads();
         }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                if (okm[qn] & (1u << c)) {
+                if ((okm[qn] & (1u << c)) && !(TB_ABL & 2)) {
                     const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
                     float4 v;
                     if (in_lds) v = *reinterpret_cast<const float4 *>(tb_smem + ((size_t)(vidx[qn] + (dz * ey + dy) * ex + dx) * 32 + part * 4) * 4);
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
                     acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, wgt[qn][c]));
                     acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, wgt[qn][c]));
                 }
-            *reinterpret_cast<float4 *>(out + mrow[qn] * ldo + cg * 32 + part * 4) = acc;
+            if (!(TB_ABL & 4)) *reinterpret_cast<float4 *>(out + mrow[qn] * ldo + cg * 32 + part * 4) = acc;
+            else if (acc.x == 12345.f) out[0] = acc.y;
         }
     }
 }
