@@ -358,6 +358,35 @@ def test_conv3d_split_against_torch(C0, C1, Cout, dims, planes, tol):
     np.testing.assert_allclose(osum.cpu().numpy(), got.sum(dim=(2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("planes", [4, 2])
+@pytest.mark.parametrize("C0,C1,Cout,dims", [(32, 0, 128, (32, 32, 64)), (16, 32, 128, (30, 34, 62)), (16, 0, 256, (16, 32, 64))])
+def test_conv3d_split_wide_variant_against_torch(C0, C1, Cout, dims, planes):
+    """shapes large enough (>= 512 workgroups, Cout % 128 == 0) to dispatch conv3d_split_wide_kernel (8 waves, shared double-buffered
+    halo, staging overlapped with the MFMA stream): against torch fp64, the fp32-MFMA kernel, ragged dims, the upsampled source"""
+    g = torch.Generator().manual_seed(C0 + C1 + Cout + planes)
+    B, (D, H, W) = 2, dims
+    assert -(-D // 4) * -(-H // 8) * -(-W // 8) * (Cout // 128) * B >= 512
+    x0 = torch.randn(B, C0, D, H, W, generator=g)
+    x1 = torch.randn(B, C1, D // 2, H // 2, W // 2, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3, generator=g) / (27 * (C0 + C1)) ** 0.5
+    gamma = torch.rand(C0 + C1, generator=g) + 0.5
+    beta = torch.randn(C0 + C1, generator=g)
+    xin = x0 if x1 is None else torch.cat((x0, F.interpolate(x1, size=(D, H, W), mode="nearest")), dim=1)
+    ref64 = F.relu(F.conv3d(F.group_norm(xin.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1))
+    s0 = x0.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    s1 = None if x1 is None else x1.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    a, d = ops.groupnorm_affine(ops.channel_stats(s0), None if s1 is None else ops.channel_stats(s1), 8, 1e-5, gamma.to(DEV), beta.to(DEV))
+    out32 = ops.conv3d_gcr(s0, s1, a, d, ops.pack_conv_weight(w).to(DEV), Cout).permute(0, 4, 1, 2, 3).cpu().double()
+    out, (osum, osq, V) = ops.conv3d_gcr_split(s0, s1, a, d, ops.pack_conv_weight_split(w, planes).to(DEV), Cout, with_stats=True)
+    got = out.permute(0, 4, 1, 2, 3).cpu().double()
+    e_split, e_f32 = (got - ref64).abs().max().item(), (out32 - ref64).abs().max().item()
+    print(f"wide mode {planes}: err vs fp64 {e_split:.2e} (fp32-MFMA kernel {e_f32:.2e})")
+    assert e_split <= (2 * max(e_f32, 2e-6) if planes == 4 else 2e-4), (e_split, e_f32)
+    np.testing.assert_allclose(osum.cpu().numpy(), got.sum(dim=(2, 3, 4)).numpy(), rtol=1e-5, atol=2e-2)
+    rs, rq, rV = ops.channel_stats(out)
+    np.testing.assert_allclose(osq.cpu().numpy(), rq.cpu().numpy(), rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("C,dims", [(16, (6, 8, 10)), (32, (8, 8, 8)), (128, (4, 6, 2)), (20, (4, 4, 4))])
 def test_maxpool(C, dims):
     x = torch.randn(2, C, *dims, generator=torch.Generator().manual_seed(C))
