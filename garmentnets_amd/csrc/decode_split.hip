@@ -30,13 +30,12 @@ typedef float f32x2q __attribute__((ext_vector_type(2)));
 #define DS_K0 128
 #define DS_N 256
 #define DS_STAGE_BYTES 16384
-#define DS_NSTAGE 24                 // 8 (layer 1: 4 block pairs x 2 k-halves) + 16 (layer 2: 4 block pairs x 4 k-quarters)
 #define DS_RING 4
 #define DS_TILE 128                  // queries per workgroup pass
 
 struct DecSplitArgs {
     const float *xin; int ldxin; long long M;
-    const unsigned char *wp;         // [24 stages][4 k-groups][2 blocks][2 planes][64 lanes] x 16 B
+    const unsigned char *wp;         // [stages][4 k-group steps][2 blocks][2 planes][64 lanes] x 16 B; step order: layer 1 (pair, k-group), layer 2
     const float *tab;                // tab1 [8][2][16] (b1) | tab2 [8][2][1+OUT][16] (b2', w3') | b3', s3, t3 [3][OUT]
     float inv1, inv2;                // exact powers of two undoing the weight scales
     float *out; int ldo;
@@ -69,9 +68,16 @@ __device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {  /
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); expcnt left at 7 (no wait)
 #define DS_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
 
-template <int OUTC>
+// K0G = 16-deep k-groups of the first layer: 8 for the plain [128, 256, 256, OUT] decoder, 2 when the UNet's final 1x1x1
+// convolution (32 -> 128, linear) has been folded into the first layer on the host (pack_decode_split(..., final_conv)): the
+// decoder then reads 32-channel rows sampled from the PRE-final feature volume.
+template <int OUTC, int K0G>
 __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitArgs p) {
     constexpr int TAB1 = 8 * 2 * 16, TAB2 = 8 * 2 * (1 + OUTC) * 16, TABN = TAB1 + TAB2 + 3 * OUTC;
+    constexpr int NS1 = 4 * K0G, NSTEPS = NS1 + 64, NSTAGE = NSTEPS / 4;   // k-group steps: layer 1 (4 pairs x K0G), layer 2 (4 x 16)
+    constexpr int NRAW = 2 * K0G;                                          // float4 row loads per lane per tile
+    constexpr int RAW_STAGE = NSTAGE - 8;                                  // where the next tile's rows are requested
+    static_assert(NSTEPS % 4 == 0 && (K0G == 2 || K0G == 8), "stage = 4 k-group steps");
     __shared__ __attribute__((aligned(16))) unsigned char smem[DS_RING * DS_STAGE_BYTES + ((TABN * 4 + 15) / 16) * 16];
     float *const tab = reinterpret_cast<float *>(smem + DS_RING * DS_STAGE_BYTES);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -81,21 +87,22 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
 
     for (int i = tid; i < TABN; i += 256) tab[i] = p.tab[i];
 
-    // each wave DMAs 4 of a stage's 16 fragments
+    // each wave DMAs 4 of a stage's 16 fragments.  Stage s of tile n sits in ring slot (n * NSTAGE + s) % 4: `sb` carries n * NSTAGE
     const unsigned char *wsrc = p.wp + (wave * 4) * 1024 + lane * 16;
+    int sb = 0;
 #define DS_ISSUE(STAGE, SLOT)                                                                                                  \
     _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
         ds_glds16(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
     DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2) DS_ISSUE(3, 3)
 
-    // first tile's rows: lane (h, r) holds the 8 channels 16g + 8h .. + 7 of query r for g = 0..7
-    float4 raw[16];
+    // first tile's rows: lane (h, r) holds the 8 channels 16g + 8h .. + 7 of query r for g = 0..K0G-1
+    float4 raw[NRAW];
     {
         long long m = (long long)blockIdx.x * DS_TILE + wave * 32 + r;
         if (m >= p.M) m = p.M - 1;
         const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
+        for (int g = 0; g < K0G; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): prologue DMAs + table stores
     __syncthreads();
@@ -107,9 +114,9 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- X0 planes from the prefetched rows
-        uint4 x0[2][8], h1[2][16];
+        uint4 x0[2][K0G], h1[2][16];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < K0G; ++g) {
             ds_split2(raw[2 * g].x, raw[2 * g].y, x0[0][g].x, x0[1][g].x);
             ds_split2(raw[2 * g].z, raw[2 * g].w, x0[0][g].y, x0[1][g].y);
             ds_split2(raw[2 * g + 1].x, raw[2 * g + 1].y, x0[0][g].z, x0[1][g].z);
@@ -118,24 +125,24 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
         float psum[OUTC];
 #pragma unroll
         for (int o = 0; o < OUTC; ++o) psum[o] = 0.f;
-        // two accumulator sets: the epilogue of block pair P-1 (VALU) is spread over the MFMAs of pair P's first stage
+        // two accumulator sets: the epilogue of block pair P-1 (VALU) is spread over the MFMAs of the steps that follow it
         f32x16q acc[2][2];
 
-        // epilogue chunk c (registers 4c..4c+3 of both blocks) of block pair P (0-3: layer 1, 4-7: layer 2)
-        auto epilogue = [&](int P, int c) {
+        // epilogue of registers [4 qd, 4 qd + 4) of both blocks of block pair P (0-3: layer 1, 4-7: layer 2)
+        auto epilogue = [&](int P, int qd) {
             const int set = P & 1;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 if (P < 4) {
                     const int nb = 2 * P + blk;
-                    const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * c);
-                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * c + 0], p.inv1, bv.x), 0.f);
-                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * c + 1], p.inv1, bv.y), 0.f);
-                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * c + 2], p.inv1, bv.z), 0.f);
-                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * c + 3], p.inv1, bv.w), 0.f);
-                    // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; chunk c fills half a fragment
-                    const int g2 = 2 * nb + (c >> 1);
-                    if (c & 1) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
+                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * qd + 0], p.inv1, bv.x), 0.f);
+                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * qd + 1], p.inv1, bv.y), 0.f);
+                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * qd + 2], p.inv1, bv.z), 0.f);
+                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * qd + 3], p.inv1, bv.w), 0.f);
+                    // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; a register quad fills half a fragment
+                    const int g2 = 2 * nb + (qd >> 1);
+                    if (qd & 1) {
                         ds_split2(v0, v1, h1[0][g2].z, h1[1][g2].z);
                         ds_split2(v2, v3, h1[0][g2].w, h1[1][g2].w);
                     } else {
@@ -144,12 +151,12 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
                     }
                 } else {
                     const int nb = 2 * (P - 4) + blk;
-                    const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * c;
+                    const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
                     const float4 bv = *reinterpret_cast<const float4 *>(tb);
-                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * c + 0], p.inv2, bv.x), 0.f);
-                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * c + 1], p.inv2, bv.y), 0.f);
-                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * c + 2], p.inv2, bv.z), 0.f);
-                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * c + 3], p.inv2, bv.w), 0.f);
+                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * qd + 0], p.inv2, bv.x), 0.f);
+                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * qd + 1], p.inv2, bv.y), 0.f);
+                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * qd + 2], p.inv2, bv.z), 0.f);
+                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * qd + 3], p.inv2, bv.w), 0.f);
 #pragma unroll
                     for (int o = 0; o < OUTC; ++o) {
                         const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
@@ -163,54 +170,63 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
         };
 
 #pragma unroll
-        for (int t = 0; t < DS_NSTAGE; ++t) {
-            const bool l1 = t < 8;
-            const int P = l1 ? (t >> 1) : 4 + ((t - 8) >> 2);              // block pair
-            const int kq = l1 ? (t & 1) : ((t - 8) & 3);                   // k-quarter (4 k-groups)
+        for (int step = 0; step < NSTEPS; ++step) {
+            const int t = step >> 2, kg = step & 3;                          // DMA stage, k-group slot inside it
+            const bool l1 = step < NS1;
+            const int P = l1 ? step / K0G : 4 + ((step - NS1) >> 4);         // block pair
+            const int g = l1 ? step % K0G : ((step - NS1) & 15);             // k-group of the layer
             const int set = P & 1;
-            if (kq == 0) {
+            if (g == 0) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[set][0][q] = 0.f; acc[set][1][q] = 0.f; }
             }
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
+            for (int f = 0; f < 4; ++f) A[f] = nA[f];
+            if (kg < 3) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) A[f] = nA[f];
-                if (kg < 3) {
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + sb) & 3) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
+            } else {
+                // ---- stage hand-over: stage t+1 has landed for everybody, stage t has been read by everybody
+                // VM queue (oldest first): stage t+1, t+2, t+3 [+ the NRAW row loads issued in stage RAW_STAGE]; see the note below
+                if (t > RAW_STAGE && t <= RAW_STAGE + 3) DS_WAIT_VM_LGKM0(8 + NRAW); else DS_WAIT_VM_LGKM0(8);
+                __builtin_amdgcn_s_barrier();
+                DS_ISSUE((t + 4) % NSTAGE, (t + sb) & 3)
+                if (t == RAW_STAGE) {                                     // next tile's rows (clamped: the last tile re-reads its own)
+                    long long tn = tile + gridDim.x;
+                    if (tn >= ntiles) tn = tile;
+                    long long m = tn * DS_TILE + wave * 32 + r;
+                    if (m >= p.M) m = p.M - 1;
+                    const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + (t % DS_RING) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
-                } else {
-                    // ---- stage hand-over: stage t+1 has landed for everybody, stage t has been read by everybody
-                    // VM queue (oldest first): stage t+1, t+2, t+3 [+ the 16 row loads issued in stage 16]; see the note below
-                    if (t >= 17 && t <= 19) DS_WAIT_VM_LGKM0(24); else DS_WAIT_VM_LGKM0(8);
-                    __builtin_amdgcn_s_barrier();
-                    DS_ISSUE((t + 4) % DS_NSTAGE, t % DS_RING)
-                    if (t == 16) {                                        // next tile's rows (clamped: the last tile re-reads its own)
-                        long long tn = tile + gridDim.x;
-                        if (tn >= ntiles) tn = tile;
-                        long long m = tn * DS_TILE + wave * 32 + r;
-                        if (m >= p.M) m = p.M - 1;
-                        const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
-#pragma unroll
-                        for (int g = 0; g < 8; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
-                    }
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1) % DS_RING) * DS_STAGE_BYTES + f * 1024);
+                    for (int gg = 0; gg < K0G; ++gg) { raw[2 * gg] = row[4 * gg]; raw[2 * gg + 1] = row[4 * gg + 1]; }
                 }
-                const int g = kq * 4 + kg;
-                const uint4 b1 = l1 ? x0[0][g & 7] : h1[0][g], b2 = l1 ? x0[1][g & 7] : h1[1][g];
-                // A: [blk0 w1, blk0 w2, blk1 w1, blk1 w2]; smallest terms first
-                acc[set][0] = ds_mfma(A[1], b1, acc[set][0]);
-                acc[set][1] = ds_mfma(A[3], b1, acc[set][1]);
-                acc[set][0] = ds_mfma(A[0], b2, acc[set][0]);
-                acc[set][1] = ds_mfma(A[2], b2, acc[set][1]);
-                acc[set][0] = ds_mfma(A[0], b1, acc[set][0]);
-                acc[set][1] = ds_mfma(A[2], b1, acc[set][1]);
-                if (kq == 0 && P > 0) epilogue(P - 1, kg);                // the previous pair's epilogue rides along
+#pragma unroll
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1 + sb) & 3) * DS_STAGE_BYTES + f * 1024);
+            }
+            const uint4 b1 = l1 ? x0[0][g % K0G] : h1[0][g], b2 = l1 ? x0[1][g % K0G] : h1[1][g];
+            // A: [blk0 w1, blk0 w2, blk1 w1, blk1 w2]; smallest terms first
+            acc[set][0] = ds_mfma(A[1], b1, acc[set][0]);
+            acc[set][1] = ds_mfma(A[3], b1, acc[set][1]);
+            acc[set][0] = ds_mfma(A[0], b2, acc[set][0]);
+            acc[set][1] = ds_mfma(A[2], b2, acc[set][1]);
+            acc[set][0] = ds_mfma(A[0], b1, acc[set][0]);
+            acc[set][1] = ds_mfma(A[2], b1, acc[set][1]);
+            // the epilogue of an earlier pair rides along: pair Pp finished at step Lp; its 4 register quads are handled during the
+            // NCH steps that follow (NCH <= K0G for layer 1, so that they are done before pair Pp + 2 reuses the accumulator set)
+#pragma unroll
+            for (int Pp = 0; Pp < 7; ++Pp) {
+                const int Lp = Pp < 4 ? (Pp + 1) * K0G - 1 : NS1 + (Pp - 3) * 16 - 1;
+                const int NCH = (Pp < 4 && K0G < 4) ? K0G : 4;
+                const int c = step - 1 - Lp;
+                if (c >= 0 && c < NCH) {
+#pragma unroll
+                    for (int qd = c * (4 / NCH); qd < (c + 1) * (4 / NCH); ++qd) epilogue(Pp, qd);
+                }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) epilogue(7, c);
+        for (int qd = 0; qd < 4; ++qd) epilogue(7, qd);
+        sb = (sb + NSTAGE) & 3;
         // ---- output layer: the two lane halves hold disjoint unit sets of the same query
         const long long m = tile * DS_TILE + wave * 32 + r;
 #pragma unroll
@@ -229,15 +245,16 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
     __syncthreads();
 }
 // Note on the counted waits.  VM operations retire in issue order.  At the hand-over of stage t the queue holds the DMAs of
-// stages t+1, t+2, t+3 (4 per wave each); stage t+1 has landed when at most 8 remain.  The 16 row loads of the next tile are
-// issued right after the DMAs of stage 20 (at the hand-over of stage 16), i.e. they sit between stage 20's and stage 21's DMAs:
-// for t = 17, 18, 19 they are younger than stage t+1, so 8 + 16 may remain; from t = 20 on they are older than the stage
-// being waited for and the plain count applies again (they had four stages = 24 x 4 MFMAs to arrive).
+// stages t+1, t+2, t+3 (4 per wave each); stage t+1 has landed when at most 8 remain.  The NRAW row loads of the next tile are
+// issued right after the DMAs of stage RAW_STAGE+4 (at the hand-over of stage RAW_STAGE): for the next three hand-overs they are
+// younger than the stage being waited for, so 8 + NRAW may remain; after that they are older and the plain count applies again
+// (they had four stages = 24 x 4 MFMAs to arrive).  The wrap-around (stage (t+4) % NSTAGE belongs to the NEXT tile; the last tile
+// fetches four stages it never uses) keeps every count independent of the tile.
 
 extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, float inv1, float inv2,
                                         int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
     GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
-    GN_REQUIRE(C0 == DS_K0 && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_split: only the [128,256,256,out] decoder is packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
+    GN_REQUIRE((C0 == 128 || C0 == 32) && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_split: only [128 | 32, 256, 256, out] decoders are packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
     GN_REQUIRE(ldxin >= C0 && ldxin % 4 == 0, "gn_implicit_decode_split: rows need a 16-byte aligned leading dimension");
     GN_REQUIRE(inv1 > 0.f && inv2 > 0.f, "gn_implicit_decode_split: bad weight scales");
     if (M == 0) return GN_OK;
@@ -247,12 +264,18 @@ extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, 
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);      // one persistent workgroup per CU
     hipStream_t st = gn_stream(stream);
+#define DS_LAUNCH(O)                                                                                                           \
+    do {                                                                                                                       \
+        if (C0 == 128) hipLaunchKernelGGL((implicit_decode_split_kernel<O, 8>), dim3(grid), dim3(256), 0, st, p);              \
+        else hipLaunchKernelGGL((implicit_decode_split_kernel<O, 2>), dim3(grid), dim3(256), 0, st, p);                        \
+    } while (0)
     switch (OUT) {
-        case 1: hipLaunchKernelGGL(implicit_decode_split_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(implicit_decode_split_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(implicit_decode_split_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(implicit_decode_split_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        case 1: DS_LAUNCH(1); break;
+        case 2: DS_LAUNCH(2); break;
+        case 3: DS_LAUNCH(3); break;
+        default: DS_LAUNCH(4); break;
     }
+#undef DS_LAUNCH
     GN_LAUNCH_CHECK("gn_implicit_decode_split");
     return GN_OK;
 }

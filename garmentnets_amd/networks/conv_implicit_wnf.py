@@ -6,6 +6,8 @@ Keeps the reference's class names, constructor kwargs, sub-module names (= check
 ``mc_surface_decoder_forward``, ``forward``) and result-dict keys, so that predict.py is a drop-in.  Training code
 (:340-452) is out of scope.  Feature volumes are stored channel-last; the (B,C,D,H,W) tensors handed out are views.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -88,9 +90,43 @@ class ImplicitWNFDecoder(PackedModule):
         split = ops.pack_decode_split(raw).to(w.device) if tuple(ch[:3]) == (128, 256, 256) else None
         return tuple(layers) + (split,)
 
-    def _decode_rows(self, vol_b, out, query=None, Q=0):
+    def folded_pack(self, final_conv):
+        """The same decoder with the UNet's final 1x1x1 convolution (linear, no activation) folded into its first layer:
+        W1' = W1 Wf, b1' = b1 + W1 bf (fp64 on the host).  It runs on rows sampled from the PRE-final feature volume (f_maps[0] = 32
+        channels instead of 128): trilinear interpolation is linear and its weights sum to one, so sample(Wf x + bf) = Wf sample(x) +
+        bf up to rounding.  The 128-channel volume is then never written or read (17 GB per 16-garment batch at 128^3), the
+        sampler moves a quarter of the bytes and layer 1 does a quarter of the FLOPs.  -> packed() layout, or None when not foldable."""
+        ch = self.nn_channels
+        if not (self.fused and len(ch) == 4 and ch[0] == final_conv.out_channels and final_conv.in_channels % 32 == 0 and ch[1] % 256 == 0
+                and ch[2] % 256 == 0 and ch[3] <= 4 and final_conv.kernel_size == (1, 1, 1)):
+            return None
+        key = (id(final_conv), final_conv.weight._version, final_conv.bias._version, final_conv.weight.device) + tuple(p._version for p in self.parameters())
+        cache = self.__dict__.setdefault("_folded", {})
+        if key not in cache:
+            cache.clear()
+            with torch.no_grad():
+                wf = final_conv.weight.detach().double().reshape(final_conv.out_channels, final_conv.in_channels)
+                bf = final_conv.bias.detach().double()
+                layers, raw = [], []
+                for i, block in enumerate(self.mlp):
+                    w = block[0].weight.detach().double()
+                    b = block[0].bias.detach().double()
+                    if i == 0:
+                        b = b + w @ bf
+                        w = w @ wf
+                    w, b = w.float(), b.float().contiguous()
+                    sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
+                    layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
+                    raw.append((w, b, sc, sh))
+                split = ops.pack_decode_split(raw).to(w.device) if (final_conv.in_channels, ch[1], ch[2]) == (32, 256, 256) else None
+                cache[key] = tuple(layers) + (split,)
+        return cache[key]
+
+    def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None):
+        """vol_b [D][H][W][C]: the decoder's own input volume, or (with the folded `layers`) the UNet's pre-final volume"""
         M = out.shape[0]
-        layers = self.packed() if self.fused else None
+        if layers is None:
+            layers = self.packed() if self.fused else None
         chunk = self.ROWS_PER_CHUNK
         if query is None:                           # lattice: whole i-slabs per chunk (the brick sampler's unit)
             chunk = max(1, chunk // (Q * Q)) * Q * Q
@@ -126,6 +162,73 @@ class ImplicitWNFDecoder(PackedModule):
         for b in range(B):
             self._decode_rows(vol[b], out[b], Q=Q)
         return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
+
+    def run_on(self, unet3d_result, query_points=None, Q=0):
+        """decode against a unet3d_forward result: through the folded first layer when the result still carries the pre-final
+        volume (UNetResult) and this decoder can absorb the final convolution, else on the materialised 128-channel volume.
+        query_points (B,M,3) -> (B,M,out); query_points None -> the (Q,Q,Q) lattice -> (B,Q,Q,Q[,out])"""
+        layers = None
+        if isinstance(unet3d_result, UNetResult) and FOLD_FINAL_CONV:
+            layers = self.folded_pack(unet3d_result.final_conv)
+        if layers is None:
+            vol = unet3d_result["out_feature_volume"]
+            return self.decode_lattice(vol, Q) if query_points is None else self(vol, query_points)
+        vol = unet3d_result.pre_final
+        B = vol.shape[0]
+        if query_points is None:
+            out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
+            for b in range(B):
+                self._decode_rows(vol[b], out[b], Q=Q, layers=layers)
+            return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
+        q = query_points.float().contiguous()
+        out = torch.empty((B, q.shape[1], self.out_channels), dtype=torch.float32, device=vol.device)
+        for b in range(B):
+            self._decode_rows(vol[b], out[b], query=q[b], layers=layers)
+        return out
+
+
+# the decoders fold the UNet's final 1x1x1 convolution into their first layer (ImplicitWNFDecoder.folded_pack); False restores the
+# reference's literal order of operations (materialise the 128-channel volume, then sample it)
+FOLD_FINAL_CONV = os.environ.get("GARMENTNETS_FOLD_FINAL_CONV", "1") != "0"
+
+
+class UNetResult(dict):
+    """unet3d_forward's result: {'out_feature_volume': (B,128,D,H,W)} as in the reference, except that the 128-channel volume is
+    only materialised (one gn_linear over all voxels) if somebody actually reads it; the decoders do not (see folded_pack)."""
+
+    def __init__(self, pre_final, final_conv):
+        super().__init__()
+        self.pre_final, self.final_conv = pre_final, final_conv          # [B][D][H][W][f_maps[0]] channel-last
+
+    def select(self, b0, b1):
+        """the same result for garments b0..b1-1 (predict.py slices out_feature_volume[[i]] per sample)"""
+        sub = UNetResult(self.pre_final[b0:b1], self.final_conv)
+        if dict.__contains__(self, "out_feature_volume"):
+            dict.__setitem__(sub, "out_feature_volume", dict.__getitem__(self, "out_feature_volume")[b0:b1])
+        return sub
+
+    def _materialise(self):
+        if not dict.__contains__(self, "out_feature_volume"):
+            dict.__setitem__(self, "out_feature_volume", self.final_conv.run(self.pre_final).permute(0, 4, 1, 2, 3))
+
+    def __getitem__(self, k):
+        if k == "out_feature_volume":
+            self._materialise()
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        return k == "out_feature_volume" or dict.__contains__(self, k)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
 
 
 class ConvImplicitWNFPipeline(nn.Module):
@@ -179,21 +282,23 @@ class ConvImplicitWNFPipeline(nn.Module):
 
     def unet3d_forward(self, pointnet2_result):
         in_feature_volume = self.volume_agg(pointnet2_result["nocs_data"])
-        return {"out_feature_volume": self.unet_3d(in_feature_volume)}
+        net = self.unet_3d.abstract_3d_unet
+        pre = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True)
+        return UNetResult(pre, net.final_conv)       # ['out_feature_volume'] materialises the reference's tensor on demand
 
     def volume_decoder_forward(self, unet3d_result, query_points):
-        out = self.volume_decoder(unet3d_result["out_feature_volume"], query_points)
+        out = self.volume_decoder.run_on(unet3d_result, query_points)
         return {"out_features": out, "pred_volume_value": out.view(*out.shape[:-1])}
 
     def surface_decoder_forward(self, unet3d_result, query_points):
-        return {"out_features": self.surface_decoder(unet3d_result["out_feature_volume"], query_points)}
+        return {"out_features": self.surface_decoder.run_on(unet3d_result, query_points)}
 
     def mc_surface_decoder_forward(self, unet3d_result, query_points):
-        return {"out_features": self.mc_surface_decoder(unet3d_result["out_feature_volume"], query_points)}
+        return {"out_features": self.mc_surface_decoder.run_on(unet3d_result, query_points)}
 
     def volume_lattice_forward(self, unet3d_result, volume_size):
         """Whole (Q,Q,Q) WNF volume per garment in one pass (replaces the 64^3 chunk loop of predict.py:145-157)."""
-        return {"pred_volume": self.volume_decoder.decode_lattice(unet3d_result["out_feature_volume"], volume_size)}
+        return {"pred_volume": self.volume_decoder.run_on(unet3d_result, None, Q=volume_size)}
 
     def forward(self, data):
         if self.volume_task_space:

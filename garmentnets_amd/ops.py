@@ -362,12 +362,14 @@ def pack_decode_split(layers):
     """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)) with w1 (256,128), w2 (256,256), w3 (OUT,256) fp32, s/t = folded
     BatchNorm scale/shift or None -> DecodeSplitPack.  The BatchNorm affine of hidden layer i is folded into layer i+1
     (W' = W diag(s), b' = b + W t, in fp64).  Weight stages: [24][4 k-groups][2 blocks][2 planes][64 lanes][8 fp16]; layer 2's k
-    order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip)."""
+    order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip).  w1 may be (256, 32):
+    the first layer with the UNet's final 1x1x1 convolution folded in (ImplicitWNFDecoder.folded_pack)."""
     (w1, b1, s1, t1), (w2, b2, s2, t2), (w3, b3, s3, t3) = layers
     dd = lambda v, n, fill: (torch.full((n,), fill, dtype=torch.float64) if v is None else v.detach().double().cpu())
     w1, w2, w3 = w1.detach().double().cpu(), w2.detach().double().cpu(), w3.detach().double().cpu()
     out_c = w3.shape[0]
-    assert w1.shape == (256, 128) and w2.shape == (256, 256) and w3.shape[1] == 256 and 1 <= out_c <= 4
+    assert w1.shape in ((256, 128), (256, 32)) and w2.shape == (256, 256) and w3.shape[1] == 256 and 1 <= out_c <= 4
+    k0g = w1.shape[1] // 16                                                                       # 16-deep k-groups of layer 1
     b2f = (dd(b2, 256, 0.0) + w2 @ dd(t1, 256, 0.0)).float()
     w2 = (w2 * dd(s1, 256, 1.0)[None, :]).float()
     b3f = (dd(b3, out_c, 0.0) + w3 @ dd(t2, 256, 0.0)).float()
@@ -375,21 +377,21 @@ def pack_decode_split(layers):
     w1, b1f = w1.float(), dd(b1, 256, 0.0).float()
     sc1, sc2 = _pow2_scale(w1), _pow2_scale(w2)
     ar = torch.arange
-    bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(2), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
-    a1 = (w1 * sc1)[32 * (2 * bp + blk) + r, 16 * (4 * kq + kg) + 8 * h + i]                     # [bp][kq][kg][blk][h][r][i]
+    bp, g1, blk, h, r, i = torch.meshgrid(ar(4), ar(k0g), ar(2), ar(2), ar(32), ar(8), indexing="ij")
+    a1 = (w1 * sc1)[32 * (2 * bp + blk) + r, 16 * g1 + 8 * h + i]                                # [pair][k-group][blk][h][r][i]
     bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(4), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
     g2 = 4 * kq + kg
     q = 8 * (g2 & 1) + i
     a2 = (w2 * sc2)[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]
 
-    def planes(a):                                                                                # -> [stage][kg][blk][plane][h][r][i]
+    def planes(a):                                   # [..steps..][blk][h][r][i] -> [stage][4 steps][blk][plane][h][r][i]
         p1 = a.to(torch.float16)
         p2 = (a - p1.float()).to(torch.float16)
-        st = torch.stack((p1, p2), dim=4)                                                         # [bp][kq][kg][blk][plane][h][r][i]
-        return st.reshape(-1, 4, 2, 2, 2, 32, 8)
+        st = torch.stack((p1, p2), dim=-4)                                                        # [...][blk][plane][h][r][i]
+        return st.reshape(-1, 4, 2, 2, 2, 32, 8)                                                  # steps in (pair, k-group) order, 4 per stage
 
-    wpack = torch.cat((planes(a1), planes(a2)), dim=0).contiguous().view(torch.int16)             # [24][...]
-    assert wpack.numel() * 2 == 24 * 16384
+    wpack = torch.cat((planes(a1), planes(a2)), dim=0).contiguous().view(torch.int16)             # [k0g + 16 stages][...]
+    assert wpack.numel() * 2 == (k0g + 16) * 16384
     nb, hh, qq = torch.meshgrid(ar(8), ar(2), ar(16), indexing="ij")
     u = 32 * nb + (qq & 3) + 8 * (qq >> 2) + 4 * hh                                               # [8][2][16]
     tab1 = b1f[u]
@@ -400,7 +402,7 @@ def pack_decode_split(layers):
 
 
 def implicit_decode_split(xin, pack, out=None):
-    """pre-sampled rows xin [M][128] -> out [M][OUT] through the [128,256,256,OUT] decoder on the 16-bit matrix cores"""
+    """pre-sampled rows xin [M][128 | 32] -> out [M][OUT] through the [128 | 32, 256, 256, OUT] decoder on the 16-bit matrix cores"""
     M, C0 = xin.shape
     if out is None:
         out = torch.empty((M, pack.out_channels), dtype=torch.float32, device=xin.device)

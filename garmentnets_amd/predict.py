@@ -39,9 +39,8 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
     with torch.no_grad():
         pointnet2_result = model.pointnet2_forward(batch)
         unet3d_result = model.unet3d_forward(pointnet2_result)
-        vol = unet3d_result["out_feature_volume"]
         nocs_data = pointnet2_result["nocs_data"]
-        B = vol.shape[0]
+        B = nocs_data.num_graphs
         wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
         ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
         results = []
@@ -54,7 +53,7 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
                 level = 0.5 * (float(mm[0]) + float(mm[1]))
             try:
                 mesh = mcu.wnf_to_mesh_gpu(wnf, level, gradient_sigma, gradient_direction)
-                u3_b = {"out_feature_volume": vol[b:b + 1]}
+                u3_b = unet3d_result.select(b, b + 1)          # the 128-channel volume is never materialised on this path
                 q = mesh["verts_f32"].view(1, -1, 3)
                 mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
                 if use_hole_prediction:
@@ -64,7 +63,7 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
                 mesh.pop("ggm", None)
                 res.update(mesh)
             except ValueError:
-                res.update(nan_placeholder(vol.device))
+                res.update(nan_placeholder(wnf.device))
             sl = slice(int(ptr[b]), int(ptr[b + 1]))
             res.update(pred_nocs=nocs_data.pos[sl], pred_nocs_confidence=nocs_data.pred_confidence[sl],
                        pred_nocs_logits=pointnet2_result["per_point_logits"][sl], input_points=batch.pos[sl], input_rgb=batch.x[sl])
