@@ -217,7 +217,14 @@ CONV_MODE_NAMES = {"fp32": CONV_FP32, "f16x2": SPLIT_F16X2, "bf16x3": SPLIT_BF16
 #          (csrc/unet_split.hip) -- measured error against fp64 is BELOW the fp32-MFMA kernel's (fewer accumulation roundings)
 #   fp32   v_mfma_f32_32x32x2_f32 (csrc/unet.hip): exact fp32 products, 1/16 of the matrix-core rate
 #   bf16x3 / bf16x2: bf16 planes, 6 / 3 products (fp32-class / preview quality)
-CONV_MODE = CONV_MODE_NAMES[os.environ.get("GARMENTNETS_CONV_MODE", "f16x2")]
+def _env_choice(name, default, choices):
+    v = os.environ.get(name, default)
+    if v not in choices:
+        raise ValueError(f"{name}={v!r}: expected one of {sorted(choices)}")
+    return v
+
+
+CONV_MODE = CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)]
 
 
 class SplitPack:
@@ -335,7 +342,7 @@ def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=
 
 
 # decoder MLP arithmetic: "f16x2" (default; csrc/decode_split.hip, same operand split as the convs) or "fp32" (csrc/decode.hip)
-DECODE_MODE = os.environ.get("GARMENTNETS_DECODE_MODE", "f16x2")
+DECODE_MODE = _env_choice("GARMENTNETS_DECODE_MODE", "f16x2", ("f16x2", "fp32"))
 
 
 class DecodeSplitPack:
