@@ -59,4 +59,8 @@ __device__ __forceinline__ void gn_glds16(const void *g, unsigned lds_addr) {
 // s_waitcnt vmcnt(N) lgkmcnt(0)   (gfx9 immediate: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt_hi[15:14])
 #define GN_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
 
+// ReLU with torch's NaN behaviour (relu(NaN) = NaN).  fmaxf(v, 0) would return 0 for a NaN and turn an upstream overflow
+// (e.g. an activation beyond the fp16 range in the split-operand kernels) into a silently wrong finite result.
+__device__ __forceinline__ float gn_relu(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ int gn_lane() { return threadIdx.x & 63; }

@@ -350,7 +350,7 @@ __device__ __forceinline__ void dec_layer(const float *__restrict__ X, int ldx, 
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                 float v = __fadd_rn(u == 0 ? acc0[q] : acc1[q], bv);
-                v = fmaxf(v, 0.f);
+                v = gn_relu(v);
                 if (sc) v = __fadd_rn(__fmul_rn(v, scv), shv);
                 if (OUTC > 0) {
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) sacc += red[(j * DEC_TM + row) * OUTC + o];
         if (m < p.M) {
-            float v = fmaxf(__fadd_rn(sacc, p.b3[o]), 0.f);
+            float v = gn_relu(__fadd_rn(sacc, p.b3[o]));
             if (p.s3) v = __fadd_rn(__fmul_rn(v, p.s3[o]), p.t3[o]);
             p.out[m * p.ldo + o] = v;
         }

@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
                 if (P < 4) {
                     const int nb = 2 * P + blk;
                     const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
-                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * qd + 0], p.inv1, bv.x), 0.f);
-                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * qd + 1], p.inv1, bv.y), 0.f);
-                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * qd + 2], p.inv1, bv.z), 0.f);
-                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * qd + 3], p.inv1, bv.w), 0.f);
+                    const float v0 = gn_relu(fmaf(acc[set][blk][4 * qd + 0], p.inv1, bv.x));
+                    const float v1 = gn_relu(fmaf(acc[set][blk][4 * qd + 1], p.inv1, bv.y));
+                    const float v2 = gn_relu(fmaf(acc[set][blk][4 * qd + 2], p.inv1, bv.z));
+                    const float v3 = gn_relu(fmaf(acc[set][blk][4 * qd + 3], p.inv1, bv.w));
                     // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; a register quad fills half a fragment
                     const int g2 = 2 * nb + (qd >> 1);
                     if (qd & 1) {
@@ -153,10 +153,10 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
                     const int nb = 2 * (P - 4) + blk;
                     const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
                     const float4 bv = *reinterpret_cast<const float4 *>(tb);
-                    const float v0 = fmaxf(fmaf(acc[set][blk][4 * qd + 0], p.inv2, bv.x), 0.f);
-                    const float v1 = fmaxf(fmaf(acc[set][blk][4 * qd + 1], p.inv2, bv.y), 0.f);
-                    const float v2 = fmaxf(fmaf(acc[set][blk][4 * qd + 2], p.inv2, bv.z), 0.f);
-                    const float v3 = fmaxf(fmaf(acc[set][blk][4 * qd + 3], p.inv2, bv.w), 0.f);
+                    const float v0 = gn_relu(fmaf(acc[set][blk][4 * qd + 0], p.inv2, bv.x));
+                    const float v1 = gn_relu(fmaf(acc[set][blk][4 * qd + 1], p.inv2, bv.y));
+                    const float v2 = gn_relu(fmaf(acc[set][blk][4 * qd + 2], p.inv2, bv.z));
+                    const float v3 = gn_relu(fmaf(acc[set][blk][4 * qd + 3], p.inv2, bv.w));
 #pragma unroll
                     for (int o = 0; o < OUTC; ++o) {
                         const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
             const float s = psum[o] + __shfl_xor(psum[o], 32);
             if (h == 0 && m < p.M) {
                 const float *t3 = tab + TAB1 + TAB2;
-                float y = fmaxf(__fadd_rn(s, t3[o]), 0.f);
+                float y = gn_relu(__fadd_rn(s, t3[o]));
                 y = __fadd_rn(__fmul_rn(y, t3[OUTC + o]), t3[2 * OUTC + o]);
                 p.out[m * p.ldo + o] = y;
             }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
                 const int64_t m = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < M) {
                     float v = __fadd_rn(acc[t][u][r], bv);
-                    if (relu) v = fmaxf(v, 0.f);
+                    if (relu) v = gn_relu(v);
                     if (bn_scale) v = __fadd_rn(__fmul_rn(v, sc), sh);
                     Y[m * ldy + n] = v;
                 }

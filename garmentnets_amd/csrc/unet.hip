@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v = tot[t][u][q];
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
                     ssq[u] = fmaf(v, v, ssq[u]);

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v = __fmul_rn(tot[t][u][q], p.out_scale);
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
                     ssq[u] = fmaf(v, v, ssq[u]);
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v = __fmul_rn(tot[t][u][q], p.out_scale);
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
                     ssq[u] = fmaf(v, v, ssq[u]);

@@ -363,6 +363,29 @@ def test_conv3d_split_against_torch(C0, C1, Cout, dims, planes, tol):
     np.testing.assert_allclose(osum.cpu().numpy(), got.sum(dim=(2, 3, 4)).numpy(), rtol=1e-5, atol=1e-3)
 
 
+def test_conv3d_f16x2_range_contract():
+    """fp16 planes: GroupNorm outputs beyond +-65504 must surface as inf/NaN (never as a wrong finite number); large but
+    representable activations (|x| ~ 3e4) stay as accurate as fp32; bf16x3 has fp32's range"""
+    g = torch.Generator().manual_seed(9)
+    B, C0, Cout, (D, H, W) = 1, 32, 32, (4, 8, 8)
+    x0 = torch.randn(B, C0, D, H, W, generator=g)
+    w = torch.randn(Cout, C0, 3, 3, 3, generator=g) / (27 * C0) ** 0.5
+    s0 = x0.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    st = ops.channel_stats(s0)
+    for gain, expect_finite in ((1.0e4, True), (1.0e6, False)):
+        gamma, beta = torch.full((C0,), gain), torch.zeros(C0)
+        a, d = ops.groupnorm_affine(st, None, 8, 1e-5, gamma.to(DEV), beta.to(DEV))
+        ref64 = F.relu(F.conv3d(F.group_norm(x0.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1))
+        out = ops.conv3d_gcr_split(s0, None, a, d, ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV), Cout).permute(0, 4, 1, 2, 3).cpu().double()
+        out3 = ops.conv3d_gcr_split(s0, None, a, d, ops.pack_conv_weight_split(w, ops.SPLIT_BF16X3).to(DEV), Cout).permute(0, 4, 1, 2, 3).cpu().double()
+        scale = ref64.abs().max().item()
+        assert torch.isfinite(out3).all() and (out3 - ref64).abs().max().item() <= 1e-5 * scale
+        if expect_finite:
+            assert torch.isfinite(out).all() and (out - ref64).abs().max().item() <= 1e-5 * scale
+        else:
+            assert not torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("planes", [4, 2])
 @pytest.mark.parametrize("C0,C1,Cout,dims", [(32, 0, 128, (32, 32, 64)), (16, 32, 128, (30, 34, 62)), (16, 0, 256, (16, 32, 64))])
 def test_conv3d_split_wide_variant_against_torch(C0, C1, Cout, dims, planes):
