@@ -94,20 +94,23 @@ __device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const 
 // distinct quads: conflict-free, and the halo shrinks to 39.4 KB.  (The earlier per-voxel pad, 80 B, was 3-way conflicted on every A
 // read; found by enumerating the real lane groups: tools/dev/lds_bank_check.py.)  P = 3: 96-byte voxels + the row pad = 2-way (no
 // conflict-free pitch exists; the per-voxel pad was 3-way).
-template <int P> struct HaloLayout {
+template <int P, int HZ = SP_HZ> struct HaloLayout {
     static constexpr int VB = P * 32;                                      // bytes per voxel
     static constexpr int ROWP = SP_HX * VB + 16;                           // bytes per halo row
-    static constexpr int BYTES = SP_HZ * SP_HY * ROWP;
-    __device__ static __forceinline__ int at(int hz, int hy, int hx) { return (hz * SP_HY + hy) * ROWP + hx * VB; }
+    static constexpr int BYTES = HZ * SP_HY * ROWP;
+    __device__ static constexpr __forceinline__ int at(int hz, int hy, int hx) { return (hz * SP_HY + hy) * ROWP + hx * VB; }
 };
 
-template <int NT, int P, bool F16>
+// MT = z-slices per wave: 1 -> tile 4 x 8 x 8; 2 -> tile 8 x 8 x 8 (wave w takes slices w and w+4).  The tall tile is for the 32-wide
+// (NT = 1) layers: twice the MFMAs per barrier, per staged voxel (halo 1000 instead of 2 x 600) and per B fragment.
+template <int NT, int P, bool F16, int MT>
 __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     constexpr int CT = NT * 32;
+    constexpr int TZ = SP_TZ * MT, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX, NF = 2 * MT;   // NF: 32-row fragments per wave
     // LDS (ONE array: a second __shared__ object makes hipcc drain the LDS-DMA queue before every ds_read):
     //   halo : HaloLayout<P> (600 voxels, P planes of 16 halfs each)
     //   ring : DEPTH x (NT*P) B fragments of 1 KB in lane order, filled by global_load_lds_dwordx4 DEPTH taps ahead
-    using HL = HaloLayout<P>;
+    using HL = HaloLayout<P, HZ>;
     constexpr int HALO_BYTES = HL::BYTES;
     constexpr int BTAP = NT * P * 1024;
     constexpr int DEPTH = (P == 2) ? 4 : 2;         // power of two; P = 3 has no LDS to spare next to its 67 KB halo
@@ -126,25 +129,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     const int ncb = p.Cout / CT;
     int tile = (int)(logical / (unsigned)ncb);
     const int cb = (int)(logical % (unsigned)ncb);
-    const int tiles_z = (p.D + 3) / 4;
+    const int tiles_z = (p.D + TZ - 1) / TZ;
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
-    const int z0 = tz * SP_TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
+    const int z0 = tz * TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
     const int n0 = cb * CT;
     const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
 
-    f32x16s acc[2][NT], tot[2][NT];
+    f32x16s acc[NF][NT], tot[NF][NT];               // fragment f = 2 m + t: z-slice wave + 4 m, y half t
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NF; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
     const int abase = HL::at(wave, r >> 3, r & 7) + 16 * h;                          // bytes; plane pl at +32*pl
-    constexpr int AF1 = 4 * HL::ROWP;
+    constexpr int AF1 = 4 * HL::ROWP, AFZ = 4 * SP_HY * HL::ROWP;                       // y half, second z-slice
     const int nslices = Cin / SP_KS;
     // B operands: the pack is in fragment order [slice][tap][Cout/32][plane][lane] (16 B per lane), so the NT*P fragments a
     // workgroup needs for one (slice, tap) step are NT*P contiguous KB.  They are DMA'd into the ring DEPTH steps ahead (no VGPRs;
@@ -176,19 +179,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             const int cs = from1 ? c0 - p.C0 : c0;
             const float *ab = p.a + (int64_t)b * Cin + c0;
             const float *db = p.d + (int64_t)b * Cin + c0;
-            constexpr int NIT = (SP_HVOX * 4 + 255) / 256;
+            constexpr int NIT = (HVOX * 4 + 255) / 256;
             const int c4 = (tid & 3) * 4;                                  // 256 % 4 == 0: the same channel quad every iteration
             const float4 av = *reinterpret_cast<const float4 *>(ab + c4);
             const float4 dv = *reinterpret_cast<const float4 *>(db + c4);
-            float4 raw[NIT];
-            bool inb[NIT];
+            // in batches of NB rows per thread (all of a batch's loads in flight before its first use; the tall tile takes two
+            // batches: 16 rows would not fit beside its 128 accumulator registers)
+            constexpr int NB = NIT <= 10 ? NIT : (NIT + 1) / 2;
+            for (int it0 = 0; it0 < NIT; it0 += NB) {
+            float4 raw[NB];
+            bool inb[NB];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256;
+            for (int itb = 0; itb < NB; ++itb) {
+                const int it = itb, idx = tid + (it0 + itb) * 256;
                 const int hv = idx >> 2;
                 const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
                 const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-                inb[it] = idx < SP_HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                inb[it] = idx < HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
                 raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (inb[it]) {
                     int64_t off;
@@ -198,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 }
             }
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256;
-                if (idx < SP_HVOX * 4) {
+            for (int itb = 0; itb < NB; ++itb) {
+                const int it = itb, idx = tid + (it0 + itb) * 256;
+                if (idx < HVOX * 4) {
                     const int hv = idx >> 2;
                     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
                     if (inb[it]) {                                          // zero padding comes AFTER the affine
@@ -215,17 +222,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                     for (int i = 0; i < P; ++i) *reinterpret_cast<uint2 *>(halo + HL::at(hv / (SP_HX * SP_HY), (hv / SP_HX) % SP_HY, hv % SP_HX) + i * 32 + c4 * 2) = pl[i];
                 }
             }
+            }
         }
         __syncthreads();                            // halo visible (and this wave's outstanding ring DMAs have landed)
         // step j = s*27 + tap lives in ring slot j % DEPTH
         const unsigned char *const ring_rd = smem + HALO_BYTES + lane * 16;
         int jcur = s * 27;
-        uint4 a0[P], a1[P], na0[P], na1[P], bf[NT][P], nbf[NT][P];
+        uint4 af[NF][P], naf[NF][P], bf[NT][P], nbf[NT][P];
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + i * 32);
-            na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + i * 32);
-        }
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int i = 0; i < P; ++i) naf[f][i] = *reinterpret_cast<const uint4 *>(halo + abase + (f >> 1) * AFZ + (f & 1) * AF1 + i * 32);
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -233,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap, ++jcur) {
 #pragma unroll
-            for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int i = 0; i < P; ++i) af[f][i] = naf[f][i];
 #pragma unroll
             for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -248,10 +257,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 const int t1 = tap + 1;
                 const int toff = HL::at(t1 / 9, (t1 / 3) % 3, t1 % 3);
 #pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + toff + i * 32);
-                    na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + toff + i * 32);
-                }
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) naf[f][i] = *reinterpret_cast<const uint4 *>(halo + abase + (f >> 1) * AFZ + (f & 1) * AF1 + toff + i * 32);
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -260,10 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             if (!(SP_ABL & 1)) SP_ISSUE_B();        // step j+DEPTH overwrites step j's slot (read by everyone before the barrier)
             __builtin_amdgcn_sched_barrier(0);
 #define SP_PROD(IA, IB)                                                                                                        \
-            _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
-                acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                        \
-                acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                        \
-            }
+            _Pragma("unroll") for (int u = 0; u < NT; ++u)                                                                     \
+                _Pragma("unroll") for (int f = 0; f < NF; ++f) acc[f][u] = mfma16<F16>(af[f][IA], bf[u][IB], acc[f][u]);
             // smallest terms first
             if (P == 3) { SP_PROD(P - 1, 0) SP_PROD(1, P - 2) SP_PROD(0, P - 1) }
             SP_PROD(1, 0) SP_PROD(0, 1) SP_PROD(0, 0)
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
         // tap 26 prefetched nothing: step j+1's fragments are read after the next slice's staging barrier; the last tap's own
         // barrier is the point after which no wave reads this slice's halo any more
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NF; ++t)
 #pragma unroll
             for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -283,21 +289,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     GN_WAIT_VM_LGKM0(0);                            // the pad-step DMAs must land before the LDS goes away
     __syncthreads();                                // the epilogue reuses the halo as scratch
     // ---- epilogue (identical to the fp32 kernel)
-    const int gz = z0 + wave;
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+            const int t = f & 1, gz = z0 + wave + 4 * (f >> 1);
             const int n = n0 + u * 32 + r;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = __fmul_rn(tot[t][u][q], p.out_scale);
+                    float v = __fmul_rn(tot[f][u][q], p.out_scale);
                     if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
@@ -564,10 +570,12 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     const int tiles = tz * p.tiles_y * p.tiles_x;
     const int Cin_total = C0 + C1;
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
+    // (MT = 2, the tall 8 x 8 x 8 tile, was measured on the 32-wide layers: 327-347 TFLOP/s vs 340 for MT = 1 -- its synchronous
+    //  staging phase is 29 % of the kernel -- so it is not dispatched)
 #define SP_LAUNCH(P_, F16_)                                                                                                    \
     do {                                                                                                                       \
-        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, P_, F16_>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);   \
-        else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);        \
+        if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, P_, F16_, 1>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_, 1>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);     \
     } while (0)
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
     const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && (int64_t)tiles * (Cout / 128) * B >= 512;

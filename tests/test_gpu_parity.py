@@ -387,13 +387,18 @@ def test_conv3d_f16x2_range_contract():
 
 
 @pytest.mark.parametrize("planes", [4, 2])
-@pytest.mark.parametrize("C0,C1,Cout,dims", [(32, 0, 128, (32, 32, 64)), (16, 32, 128, (30, 34, 62)), (16, 0, 256, (16, 32, 64))])
+@pytest.mark.parametrize("C0,C1,Cout,dims", [(32, 0, 128, (32, 32, 64)), (16, 32, 128, (30, 34, 62)), (16, 0, 256, (16, 32, 64)),
+                                              (32, 0, 32, (64, 32, 64)), (16, 16, 32, (62, 30, 66))])
 def test_conv3d_split_wide_variant_against_torch(C0, C1, Cout, dims, planes):
-    """shapes large enough (>= 512 workgroups, Cout % 128 == 0) to dispatch conv3d_split_wide_kernel (8 waves, shared double-buffered
-    halo, staging overlapped with the MFMA stream): against torch fp64, the fp32-MFMA kernel, ragged dims, the upsampled source"""
+    """shapes large enough (>= 512 workgroups) to dispatch the big-volume variants -- conv3d_split_wide_kernel (Cout % 128 == 0: 8 waves,
+    shared double-buffered halo, staging overlapped with the MFMA stream) and the tall-tile 32-wide kernel (Cout == 32, 8 x 8 x 8 tiles):
+    against torch fp64, the fp32-MFMA kernel, ragged dims, the upsampled source"""
     g = torch.Generator().manual_seed(C0 + C1 + Cout + planes)
     B, (D, H, W) = 2, dims
-    assert -(-D // 4) * -(-H // 8) * -(-W // 8) * (Cout // 128) * B >= 512
+    if Cout % 128 == 0:
+        assert -(-D // 4) * -(-H // 8) * -(-W // 8) * (Cout // 128) * B >= 512       # conv3d_split_wide_kernel
+    else:
+        assert Cout == 32 and -(-D // 8) * -(-H // 8) * -(-W // 8) * B >= 512         # the tall-tile (8 x 8 x 8) variant of the 32-wide kernel
     x0 = torch.randn(B, C0, D, H, W, generator=g)
     x1 = torch.randn(B, C1, D // 2, H // 2, W // 2, generator=g) if C1 else None
     w = torch.randn(Cout, C0 + C1, 3, 3, 3, generator=g) / (27 * (C0 + C1)) ** 0.5
