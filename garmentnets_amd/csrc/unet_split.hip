@@ -500,10 +500,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     constexpr int AF1 = 4 * HL::ROWP;
     const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (cg * NT * P) * 1024 + lane * 16;
     int jcur = 0;
+    uint4 bf[NT][P];                                // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (u * P + i) * 1024);
     for (int s = 0; s < nslices; ++s) {
         const unsigned char *const halo = smem + (s & 1) * HALO_BYTES;
         const int sn = s + 1 < nslices ? s + 1 : s;
-        uint4 a0[P], a1[P], na0[P], na1[P], bf[NT][P];
+        uint4 a0[P], a1[P], na0[P], na1[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + i * 32);
@@ -513,17 +518,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
         for (int tap = 0; tap < 27; ++tap, ++jcur) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
-            // hand-over: step j's fragments have landed for everybody and everybody is done with step j-1's slot.  VM queue,
-            // oldest first: fragment steps j .. j+DEPTH-2 and, for taps 1-3, the NIT row loads issued at tap 0 (younger than the
-            // DMA of tap 0, older than the DMA of tap 1): they may still be in flight there
-            if (tap >= 1 && tap <= 3) GN_WAIT_VM_LGKM0((DEPTH - 2) * CH + NIT); else GN_WAIT_VM_LGKM0((DEPTH - 2) * CH);
+            // hand-over: step j+1's fragments have landed for everybody (they are read at the END of this tap, into the registers the
+            // MFMAs of this tap have just consumed: no register double buffer, no LDS latency after the barrier) and everybody is done
+            // with step j-1's slot.  VM queue, oldest first: fragment steps j+1 .. j+DEPTH-2 and, for taps 1-2, the NIT row loads
+            // issued at tap 0 (younger than the DMA of tap 0 = step j0+DEPTH-1): they may still be in flight there
+            if (tap >= 1 && tap <= 2) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH + NIT); else GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
             __builtin_amdgcn_s_barrier();
-            SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 just vacated
-            // B fragments are read straight after the barrier (no register double buffer: 16 VGPRs the kernel does not have)
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-#pragma unroll
-                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (jcur & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
+            SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
             if (tap + 1 < 27) {
                 const int t1 = tap + 1;
                 const int toff = HL::at(t1 / 9, (t1 / 3) % 3, t1 % 3);
@@ -544,6 +545,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             if (tap >= 8 && tap < 8 + NIT && s + 1 < nslices) convert_row(tap - 8, sn, (s + 1) & 1);
             SPW_PROD(0, 1) SPW_PROD(0, 0)
 #undef SPW_PROD
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
