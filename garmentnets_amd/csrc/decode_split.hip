@@ -64,11 +64,16 @@ __device__ __forceinline__ f32x16q ds_mfma(const uint4 &a, const uint4 &b, const
 __device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {  // = gn_glds16 (common.h)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
 }
+// the same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset: no 64-bit VALU address arithmetic per piece
+__device__ __forceinline__ void ds_glds16_s(const void *sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); expcnt left at 7 (no wait)
 #define DS_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
 
-// K0G = 16-deep k-groups of the first layer: 8 for the plain [128, 256, 256, OUT] decoder, 2 when the UNet's final 1x1x1
+// K0G = 16-deep k-groups of the first layer: 8 for the plain [128, 256, 256, OUT] decoder (the non-default path: its 448 live
+// registers no longer fit without ~40 spilled values since the NaN-propagating ReLU, 0.34 ms per 262144 rows), 2 when the UNet's final 1x1x1
 // convolution (32 -> 128, linear) has been folded into the first layer on the host (pack_decode_split(..., final_conv)): the
 // decoder then reads 32-channel rows sampled from the PRE-final feature volume.
 template <int OUTC, int K0G>
@@ -88,11 +93,14 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
     for (int i = tid; i < TABN; i += 256) tab[i] = p.tab[i];
 
     // each wave DMAs 4 of a stage's 16 fragments.  Stage s of tile n sits in ring slot (n * NSTAGE + s) % 4: `sb` carries n * NSTAGE
-    const unsigned char *wsrc = p.wp + (wave * 4) * 1024 + lane * 16;
-    int sb = 0;
+    const unsigned char *wsrc = p.wp + (wave * 4) * 1024;   // wave-uniform (SGPRs); the lane adds 16 * lane
+    const unsigned lane16 = lane * 16;
+    int sb = 0;                                     // stays 0 (and folds away) when NSTAGE % 4 == 0
+    constexpr bool SB_ZERO = (NSTAGE % 4 == 0);
+#define DS_SB (SB_ZERO ? 0 : sb)
 #define DS_ISSUE(STAGE, SLOT)                                                                                                  \
     _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
-        ds_glds16(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
+        ds_glds16_s(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lane16, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
     DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2) DS_ISSUE(3, 3)
 
     // first tile's rows: lane (h, r) holds the 8 channels 16g + 8h .. + 7 of query r for g = 0..K0G-1
@@ -184,13 +192,13 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
             for (int f = 0; f < 4; ++f) A[f] = nA[f];
             if (kg < 3) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + sb) & 3) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + DS_SB) & 3) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
             } else {
                 // ---- stage hand-over: stage t+1 has landed for everybody, stage t has been read by everybody
                 // VM queue (oldest first): stage t+1, t+2, t+3 [+ the NRAW row loads issued in stage RAW_STAGE]; see the note below
                 if (t > RAW_STAGE && t <= RAW_STAGE + 3) DS_WAIT_VM_LGKM0(8 + NRAW); else DS_WAIT_VM_LGKM0(8);
                 __builtin_amdgcn_s_barrier();
-                DS_ISSUE((t + 4) % NSTAGE, (t + sb) & 3)
+                DS_ISSUE((t + 4) % NSTAGE, (t + DS_SB) & 3)
                 if (t == RAW_STAGE) {                                     // next tile's rows (clamped: the last tile re-reads its own)
                     long long tn = tile + gridDim.x;
                     if (tn >= ntiles) tn = tile;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
                     for (int gg = 0; gg < K0G; ++gg) { raw[2 * gg] = row[4 * gg]; raw[2 * gg + 1] = row[4 * gg + 1]; }
                 }
 #pragma unroll
-                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1 + sb) & 3) * DS_STAGE_BYTES + f * 1024);
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1 + DS_SB) & 3) * DS_STAGE_BYTES + f * 1024);
             }
             const uint4 b1 = l1 ? x0[0][g % K0G] : h1[0][g], b2 = l1 ? x0[1][g % K0G] : h1[1][g];
             // A: [blk0 w1, blk0 w2, blk1 w1, blk1 w2]; smallest terms first
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
         }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) epilogue(7, qd);
-        sb = (sb + NSTAGE) & 3;
+        if (!SB_ZERO) sb = (sb + NSTAGE) & 3;
         // ---- output layer: the two lane halves hold disjoint unit sets of the same query
         const long long m = tile * DS_TILE + wave * 32 + r;
 #pragma unroll
@@ -241,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
         }
     }
 #undef DS_ISSUE
+#undef DS_SB
     __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the wrapped-around DMAs must land before the LDS goes away
     __syncthreads();
 }

@@ -5,16 +5,17 @@ from garmentnets_amd import ops
 dev = 'cuda'
 M = 1 << 18
 out_ch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+K0 = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 g = torch.Generator().manual_seed(0)
-dims = [128, 256, 256, out_ch]
+dims = [K0, 256, 256, out_ch]
 raw = []
 for i in range(3):
     raw.append((torch.randn(dims[i + 1], dims[i], generator=g) * (2.0 / dims[i]) ** 0.5, torch.randn(dims[i + 1], generator=g) * 0.1,
                 torch.rand(dims[i + 1], generator=g) + 0.5, torch.randn(dims[i + 1], generator=g) * 0.1))
-xin = ops.new_rows(M, 128, dev); xin.copy_(torch.randn(M, 128, generator=g).to(dev))
+xin = ops.new_rows(M, K0, dev); xin.copy_(torch.randn(M, K0, generator=g).to(dev))
 pk = ops.pack_decode_split(raw).to(dev)
 layers = tuple((ops.pack_kpair(w).to(dev) if i < 2 else w.contiguous().to(dev), b.to(dev), sc.to(dev), sh.to(dev), dims[i + 1]) for i, (w, b, sc, sh) in enumerate(raw))
-fl = 2.0 * M * (128 * 256 + 256 * 256 + 256 * out_ch)
+fl = 2.0 * M * (K0 * 256 + 256 * 256 + 256 * out_ch)
 def t(f, reps=8):
     f(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
