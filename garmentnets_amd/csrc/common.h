@@ -57,6 +57,8 @@ __device__ __forceinline__ void gn_glds16(const void *g, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
 }
 // s_waitcnt vmcnt(N) lgkmcnt(0)   (gfx9 immediate: vmcnt[3:0] | expcnt[6:4] = 7 (no wait) | lgkmcnt[11:8] | vmcnt_hi[15:14])
+// s_waitcnt vmcnt(N) alone (lgkmcnt field = 15: no wait)
+#define GN_WAIT_VM_ONLY(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | 0xF00 | (((N) >> 4) << 14))
 #define GN_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | 0x70 | (((N) >> 4) << 14))
 
 // ReLU with torch's NaN behaviour (relu(NaN) = NaN).  fmaxf(v, 0) would return 0 for a NaN and turn an upstream overflow

@@ -522,7 +522,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             // MFMAs of this tap have just consumed: no register double buffer, no LDS latency after the barrier) and everybody is done
             // with step j-1's slot.  VM queue, oldest first: fragment steps j+1 .. j+DEPTH-2 and, for taps 1-2, the NIT row loads
             // issued at tap 0 (younger than the DMA of tap 0 = step j0+DEPTH-1): they may still be in flight there
-            if (tap >= 1 && tap <= 2) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH + NIT); else GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
+            // (vmcnt only: the B fragments of this step were requested a few instructions ago, at the end of the previous tap -- hipcc
+            //  waits for each of them right before the MFMA that consumes it; a blanket lgkmcnt(0) here would expose their LDS
+            //  latency at every barrier.  The slot the DMA below overwrites, step j-1's, was consumed by MFMAs every wave has issued.
+            //  Tap 26 drains the LDS queue once per slice so that the staged rows of the next slice are visible after its barriers.)
+            if (tap == 26) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
+            else if (tap >= 1 && tap <= 2) GN_WAIT_VM_ONLY((DEPTH - 3) * CH + NIT);
+            else GN_WAIT_VM_ONLY((DEPTH - 3) * CH);
             __builtin_amdgcn_s_barrier();
             SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
             if (tap + 1 < 27) {
