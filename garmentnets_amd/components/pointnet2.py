@@ -14,13 +14,28 @@ import torch
 from .. import ops
 
 
+_PTR_CACHE = {}      # (sizes, device) -> device int32 CSR ptr.  Batch shapes repeat from step to step: no per-step host-to-device copy,
+                     # and nothing that a HIP-graph capture of the forward pass could not record (garmentnets_amd/graphs.py)
+
+
+def _csr_ptr(sizes, device):
+    key = (tuple(sizes), str(device))
+    ptr = _PTR_CACHE.get(key)
+    if ptr is None:
+        if len(_PTR_CACHE) >= 256:
+            _PTR_CACHE.clear()
+        ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).to(device)
+        _PTR_CACHE[key] = ptr
+    return ptr
+
+
 class Segments:
     """Sorted batch vector in CSR form: host sizes, device int32 ptr, lazily materialised int64 batch vector."""
 
     def __init__(self, sizes, device, batch=None):
         self.sizes = [int(s) for s in sizes]
         self.device = device
-        self.ptr = torch.tensor(np.concatenate([[0], np.cumsum(self.sizes)]), dtype=torch.int32).to(device, non_blocking=True)
+        self.ptr = _csr_ptr(self.sizes, device)
         self._batch = batch
 
     @staticmethod
