@@ -277,6 +277,23 @@ def test_degenerate_sizes():
     out = ops.knn_interpolate(xs.to(DEV), ps.to(DEV), Segments([2], DEV).ptr, pq.to(DEV), Segments([3], DEV).ptr, 3)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
     assert np.allclose(out[2].cpu().numpy(), [1.0, 2.0], atol=1e-5)       # coincident point: weight 1/1e-16 dominates
+    # the split-operand entries: empty batch / no rows / no queries are no-ops; bad modes and widths are refused with GN_EINVAL
+    w = torch.randn(32, 16, 3, 3, 3)
+    pk = ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV)
+    e = ops.conv3d_gcr_split(torch.zeros(0, 4, 8, 8, 16, device=DEV), None, torch.zeros(0, 16, device=DEV), torch.zeros(0, 16, device=DEV), pk, 32)
+    assert e.shape == (0, 4, 8, 8, 32)
+    with pytest.raises(ValueError):
+        ops.conv3d_gcr_split(torch.zeros(1, 4, 8, 8, 16, device=DEV), None, torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV),
+                             ops.SplitPack(pk.tensor, 7, 1.0), 32)
+    raw = [(torch.randn(256, 32), torch.randn(256), None, None), (torch.randn(256, 256), torch.randn(256), None, None), (torch.randn(1, 256), torch.randn(1), None, None)]
+    dp = ops.pack_decode_split(raw).to(DEV)
+    assert ops.implicit_decode_split(ops.new_rows(0, 32, DEV), dp).shape == (0, 1)
+    with pytest.raises(ValueError):
+        ops.implicit_decode_split(ops.new_rows(5, 64, DEV), dp)            # 64-wide rows: not a packed first-layer width
+    i0, d0 = ops.nearest_neighbor(torch.zeros(0, 3, device=DEV), torch.zeros(4, 3, device=DEV))
+    assert i0.shape == (0,) and d0.shape == (0,)
+    with pytest.raises(ValueError):
+        ops.nearest_neighbor(torch.zeros(3, 3, device=DEV), torch.zeros(0, 3, device=DEV))
 
 
 def test_sa_module_graph_bit_exact():
