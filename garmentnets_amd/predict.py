@@ -44,6 +44,18 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
         wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
         ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
         results = []
+        # iso-surfaces of the whole batch with one host synchronisation (fixed level); auto_level needs each volume's range first
+        meshes = None if auto_level else mcu.wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level, gradient_sigma, gradient_direction)
+        # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
+        bins = model.pointnet2_nocs.nocs_bins
+        glog_all = pointnet2_result["global_logits"].reshape(B, bins, 3)
+        grip_global = torch.argmax(glog_all, dim=1).to(torch.float32) * (1.0 / (bins - 1))
+        conf_global = torch.softmax(glog_all, dim=1)
+        sizes = list(nocs_data.sizes)
+        grip_idx = None
+        if len(set(sizes)) == 1 and sizes[0] > 0:          # equal clouds: one batched arg-min (ragged batches fall back to per-garment)
+            grip_idx = torch.argmin(torch.norm(batch.pos.view(B, sizes[0], 3), dim=2), dim=1) + torch.arange(B, device=batch.pos.device) * sizes[0]
+            grip_nocs = nocs_data.pos[grip_idx]
         for b in range(B):
             wnf = wnf_all[b]
             res = dict(wnf_volume=wnf)
@@ -52,7 +64,12 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
                 mm = torch.stack([wnf.min(), wnf.max()]).cpu()
                 level = 0.5 * (float(mm[0]) + float(mm[1]))
             try:
-                mesh = mcu.wnf_to_mesh_gpu(wnf, level, gradient_sigma, gradient_direction)
+                if meshes is None:
+                    mesh = mcu.wnf_to_mesh_gpu(wnf, level, gradient_sigma, gradient_direction)
+                elif isinstance(meshes[b], Exception):       # ValueError -> placeholder below; RuntimeError propagates, as in predict.py
+                    raise meshes[b]
+                else:
+                    mesh = meshes[b]
                 u3_b = unet3d_result.select(b, b + 1)          # the 128-channel volume is never materialised on this path
                 q = mesh["verts_f32"].view(1, -1, 3)
                 mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
@@ -67,12 +84,8 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
             sl = slice(int(ptr[b]), int(ptr[b + 1]))
             res.update(pred_nocs=nocs_data.pos[sl], pred_nocs_confidence=nocs_data.pred_confidence[sl],
                        pred_nocs_logits=pointnet2_result["per_point_logits"][sl], input_points=batch.pos[sl], input_rgb=batch.x[sl])
-            # grip-point post-processing, predict.py:254-274 (tiny per-garment reductions: plain torch on device tensors)
-            bins = model.pointnet2_nocs.nocs_bins
-            glog = pointnet2_result["global_logits"][b].reshape(bins, 3)
-            res.update(pred_global_nocs_grip_point=torch.argmax(glog, dim=0).to(torch.float32) * (1.0 / (bins - 1)),
-                       pred_global_confidence=torch.softmax(glog, dim=0),
-                       pred_nocs_grip_point=nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
+            res.update(pred_global_nocs_grip_point=grip_global[b], pred_global_confidence=conf_global[b],
+                       pred_nocs_grip_point=grip_nocs[b] if grip_idx is not None else nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
                        global_feature=pointnet2_result["global_feature"][b])
             results.append(res)
         return results

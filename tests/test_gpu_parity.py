@@ -265,6 +265,25 @@ def test_pipeline_ragged_batch_against_oracle():
     np.testing.assert_allclose(vol.cpu().numpy(), rvol.numpy(), rtol=0, atol=TOL)
 
 
+def test_batched_isosurface_tail_equals_per_garment():
+    """wnf_batch_to_meshes_gpu (one host synchronisation for the batch) == wnf_to_mesh_gpu per garment, bit for bit, including
+    the error contract (level outside a volume's range -> ValueError entry)"""
+    from garmentnets_amd.common import marching_cubes_util as MCU
+    base = torch.from_numpy(S.shell_volume(24)).float()
+    noise = torch.rand(3, 24, 24, 24, generator=torch.Generator().manual_seed(4)) * 0.05
+    vols = (base[None] + noise).to(DEV)
+    vols[1] = vols[1] * 0.2                          # range [0, ~0.21]: level 0.5 is outside
+    for use_graphs in (True, False, True):           # graph capture, plain launches, graph replay from the cache
+        MCU.USE_ISO_GRAPHS = use_graphs
+        batch = MCU.wnf_batch_to_meshes_gpu(vols, 0.5, 0.5, "ascent")
+        assert isinstance(batch[1], ValueError)
+        for b in (0, 2):
+            one = MCU.wnf_to_mesh_gpu(vols[b], 0.5, 0.5, "ascent")
+            for k in one:
+                assert torch.equal(one[k], batch[b][k]), (use_graphs, k)
+    MCU.USE_ISO_GRAPHS = True
+
+
 def test_degenerate_sizes():
     """zero-row launches are no-ops; k-NN with fewer sources than k uses what exists (as the oracle does)"""
     z = ops.linear(torch.zeros(0, 8, device=DEV), torch.zeros(4, 8, device=DEV))
