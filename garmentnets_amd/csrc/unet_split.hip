@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 
     // PRE (the 32-wide kernels, where the registers exist): a thread stages the same halo voxels in every slice, so their index
     // arithmetic (halo coordinates by magic division, bounds, 64-bit offsets) is done once -- it was more than half of the staging
-    // VALU work.  goff0 / goff1: element offset of the voxel's channel quad within the sample in src0 / the half-resolution src1
-    // (-1 = outside the volume or past the last item); loff: its byte offset in the LDS halo.
+    // VALU work.  goff0 / goff1: index of the voxel within the sample in src0 / the half-resolution src1 (-1 = outside the volume or
+    // past the last item; voxel indices, not element offsets: 256^3 x 128 channels does not fit 32 bits); loff: its byte offset in
+    // the LDS halo.
     constexpr bool PRE = (NT == 1 && MT == 1);
     constexpr int NITP = (HVOX * 4 + 255) / 256;
     int goff0[PRE ? NITP : 1], goff1[PRE ? NITP : 1], loff[PRE ? NITP : 1];
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool in = idx < HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            goff0[it] = in ? ((gz * p.H + gy) * p.W + gx) * p.C0 + c4 : -1;
-            goff1[it] = in ? (((gz >> 1) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * p.C1 + c4 : -1;
+            goff0[it] = in ? (gz * p.H + gy) * p.W + gx : -1;
+            goff1[it] = in ? ((gz >> 1) * H1 + (gy >> 1)) * W1 + (gx >> 1) : -1;
             loff[it] = idx < HVOX * 4 ? HL::at(hz, hy, hx) + c4 * 2 : -1;
         }
     }
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
         // (every halo read of the previous slice completed before its last tap's barrier: the halo can be overwritten)
         if (PRE && (!(SP_ABL & 2) || s == 0)) {
             const bool from1 = c0 >= p.C0;
-            const float *base = from1 ? p.src1 + (int64_t)b * D1 * H1 * W1 * p.C1 + (c0 - p.C0) : p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0 + c0;
             const int c4 = (tid & 3) * 4;
+            const float *base = (from1 ? p.src1 + (int64_t)b * D1 * H1 * W1 * p.C1 + (c0 - p.C0) : p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0 + c0) + c4;
+            const int64_t Cs = from1 ? p.C1 : p.C0;
             const float4 av = *reinterpret_cast<const float4 *>(p.a + (int64_t)b * Cin + c0 + c4);
             const float4 dv = *reinterpret_cast<const float4 *>(p.d + (int64_t)b * Cin + c0 + c4);
             float4 raw[NITP];
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             for (int it = 0; it < NITP; ++it) {
                 const int go = from1 ? goff1[PRE ? it : 0] : goff0[PRE ? it : 0];
                 raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (go >= 0) raw[it] = *reinterpret_cast<const float4 *>(base + go);
+                if (go >= 0) raw[it] = *reinterpret_cast<const float4 *>(base + go * Cs);
             }
 #pragma unroll
             for (int it = 0; it < NITP; ++it) {
