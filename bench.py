@@ -194,6 +194,31 @@ def main():
     verts_total = sum(int(r["verts"].shape[0]) for r in res)
     assert not any(bool(torch.isnan(r["verts"]).any()) for r in res), "marching cubes produced a placeholder mesh"
 
+    # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods
+    stages_ms = None
+    if rank == 0:
+        from garmentnets_amd.common import marching_cubes_util as mcu
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        with torch.no_grad():
+            ev[0].record()
+            p2 = model.pointnet2_forward(data)
+            ev[1].record()
+            u3 = model.unet3d_forward(p2)
+            ev[2].record()
+            wnf_all = model.volume_lattice_forward(u3, args.volume_size)["pred_volume"]
+            ev[3].record()
+            lvl = 0.5
+            if auto_level:
+                mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
+                lvl = 0.5 * (float(mm[0]) + float(mm[1]))
+            for b_, mesh in enumerate(mcu.wnf_batch_to_meshes_gpu(wnf_all, lvl, 0.5, "ascent")):
+                if isinstance(mesh, dict):
+                    model.surface_decoder_forward(u3.select(b_, b_ + 1), mesh["verts_f32"].view(1, -1, 3))
+            ev[4].record()
+        torch.cuda.synchronize()
+        names = ("pointnet2_forward", "unet3d_forward (gridding + UNet)", "volume_lattice_forward (sampler + decoder)", "GGM + MC33 + surface decode")
+        stages_ms = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+
     # the only collective: per-rank (garments, seconds) over RCCL/xGMI
     per_rank = parallel.gather_metrics([args.batch * args.steps, dt], device=dev)
     if rank == 0:
@@ -222,6 +247,7 @@ def main():
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level else 0.5,
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
+            "stages_ms": stages_ms,
             "roofline": {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "peak_note": peak_note,
                          "traffic": measured_traffic(args, key),
