@@ -77,7 +77,11 @@ __device__ __forceinline__ void ds_glds16_s(const void *sbase, unsigned voff, un
 // convolution (32 -> 128, linear) has been folded into the first layer on the host (pack_decode_split(..., final_conv)): the
 // decoder then reads 32-channel rows sampled from the PRE-final feature volume.
 template <int OUTC, int K0G>
-__global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitArgs p) {
+__global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit_decode_split_kernel(DecSplitArgs p) {
+    // K0G = 2: the first-layer planes are 16 registers instead of 64, which leaves room for TWO workgroups per CU (2 waves per SIMD:
+    // one wave's epilogue / load work overlaps the other's MFMAs by itself) with a single accumulator set and an immediate epilogue
+    // (scalar output only: the 2-4 output variants need the registers of the second wave for their w3 tables)
+    constexpr int NSETS = (K0G <= 2 && OUTC == 1) ? 1 : 2;
     constexpr int TAB1 = 8 * 2 * 16, TAB2 = 8 * 2 * (1 + OUTC) * 16, TABN = TAB1 + TAB2 + 3 * OUTC;
     constexpr int NS1 = 4 * K0G, NSTEPS = NS1 + 64, NSTAGE = NSTEPS / 4;   // k-group steps: layer 1 (4 pairs x K0G), layer 2 (4 x 16)
     constexpr int NRAW = 2 * K0G;                                          // float4 row loads per lane per tile
@@ -134,11 +138,11 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
 #pragma unroll
         for (int o = 0; o < OUTC; ++o) psum[o] = 0.f;
         // two accumulator sets: the epilogue of block pair P-1 (VALU) is spread over the MFMAs of the steps that follow it
-        f32x16q acc[2][2];
+        f32x16q acc[NSETS][2];
 
         // epilogue of registers [4 qd, 4 qd + 4) of both blocks of block pair P (0-3: layer 1, 4-7: layer 2)
         auto epilogue = [&](int P, int qd) {
-            const int set = P & 1;
+            const int set = P & (NSETS - 1);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 if (P < 4) {
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
             const bool l1 = step < NS1;
             const int P = l1 ? step / K0G : 4 + ((step - NS1) >> 4);         // block pair
             const int g = l1 ? step % K0G : ((step - NS1) & 15);             // k-group of the layer
-            const int set = P & 1;
+            const int set = P & (NSETS - 1);
             if (g == 0) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[set][0][q] = 0.f; acc[set][1][q] = 0.f; }
@@ -220,15 +224,24 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split_kernel(DecSplitA
             acc[set][0] = ds_mfma(A[0], b1, acc[set][0]);
             acc[set][1] = ds_mfma(A[2], b1, acc[set][1]);
             // the epilogue of an earlier pair rides along: pair Pp finished at step Lp; its 4 register quads are handled during the
-            // NCH steps that follow (NCH <= K0G for layer 1, so that they are done before pair Pp + 2 reuses the accumulator set)
+            // NCH steps that follow (NCH <= K0G for layer 1, so that they are done before pair Pp + 2 reuses the accumulator set).
+            // With a single accumulator set the pair's epilogue runs right after its last step instead.
+            if (NSETS == 2) {
 #pragma unroll
-            for (int Pp = 0; Pp < 7; ++Pp) {
-                const int Lp = Pp < 4 ? (Pp + 1) * K0G - 1 : NS1 + (Pp - 3) * 16 - 1;
-                const int NCH = (Pp < 4 && K0G < 4) ? K0G : 4;
-                const int c = step - 1 - Lp;
-                if (c >= 0 && c < NCH) {
+                for (int Pp = 0; Pp < 7; ++Pp) {
+                    const int Lp = Pp < 4 ? (Pp + 1) * K0G - 1 : NS1 + (Pp - 3) * 16 - 1;
+                    const int NCH = (Pp < 4 && K0G < 4) ? K0G : 4;
+                    const int c = step - 1 - Lp;
+                    if (c >= 0 && c < NCH) {
 #pragma unroll
-                    for (int qd = c * (4 / NCH); qd < (c + 1) * (4 / NCH); ++qd) epilogue(Pp, qd);
+                        for (int qd = c * (4 / NCH); qd < (c + 1) * (4 / NCH); ++qd) epilogue(Pp, qd);
+                    }
+                }
+            } else {
+                const int Lp = P < 4 ? (P + 1) * K0G - 1 : NS1 + (P - 3) * 16 - 1;
+                if (step == Lp && P < 7) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) epilogue(P, qd);
                 }
             }
         }
@@ -271,7 +284,8 @@ extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, 
     DecSplitArgs p;
     p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.inv1 = inv1; p.inv2 = inv2; p.out = out; p.ldo = ldo;
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
-    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);      // one persistent workgroup per CU
+    const int64_t slots = (C0 == 32 && OUT == 1) ? 512 : 256;                       // persistent workgroups: two per CU when they fit (K0G = 2), else one
+    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipStream_t st = gn_stream(stream);
 #define DS_LAUNCH(O)                                                                                                           \
     do {                                                                                                                       \
