@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- end-to-end GarmentNets inference throughput on MI355X (BASELINE.json metric).
+"""bench.py -- GarmentNets inference throughput on MI355X (BASELINE.json metric: garments/s end to end).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                       # default = BASELINE config[2]: full pipeline, B=16/GPU, G=128, Q=128
+    python bench.py --workload full --volume-size 256 --batch 8         # config[4]: 256^3 WNF + marching cubes
+    python bench.py --workload pointnet2 --batch 32                     # config[1]: PointNet++ NOCS forward only
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One "step" = one pass of the whole hot path (predict.py:138-209: PointNet++ -> gridding -> 3-D UNet -> (Q,Q,Q) WNF
-decode -> Gaussian gradient magnitude -> Lewiner marching cubes -> surface decode) over one batch of synthetic garments
-that is already resident in HBM.  Every rank owns its own batch (weak scaling, garments never move between GPUs);
-the only collective is an all-gather of per-rank timings (RCCL).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (predict.py:138-209: PointNet++ -> gridding -> 3-D UNet -> (Q,Q,Q) WNF decode -> Gaussian
+gradient magnitude -> Lewiner marching cubes -> surface decode) over one batch of synthetic garments.  The GLOBAL batch
+(batch x world garments, one seed) is sharded contiguously over the ranks with parallel.shard_range: config[3] (128 garments over 8
+GPUs) is literally what runs under --gpus 8.  Garments never move between GPUs; the only collective is an all-gather of per-rank
+timings (RCCL).  Rank 0 prints ONE JSON line:
 
-roofline: the dominant kernel is the 3x3x3 conv (conv3d_gcr_kernel, fp32 MFMA).  Its launches are bracketed with HIP
-events on the launch stream during the timed steps; achieved = algorithmic FLOPs (54*Cin*Cout*voxels per launch) / time.
-cpu_baseline: the CPU oracle (torch-CPU port of the reference path) timed on this host for a bounded sample.
+  value / ms_per_step   K timed steps, inputs resident in HBM, results left on the device (barrier + synchronize on both sides, MAX
+                        over ranks) -- the default arithmetic (f16x2 operand split for the 3x3x3 convs and the decoder MLPs)
+  strict_fp32           the same K steps with --conv-mode fp32 --decode-mode fp32 (v_mfma_f32_32x32x2_f32 everywhere), own roofline
+  with_host_io          the same K steps including the H2D copy of the clouds and the D2H copy of every mesh (predict.to_host): the
+                        metric as SURVEY.md 8d words it
+  roofline              dominant kernel by time: launches bracketed with HIP events on the launch stream during the timed steps,
+                        labelled with the kernel variant the C ABI reports having launched (gn_last_kernel), achieved = algorithmic
+                        FLOPs (54*Cin*Cout per voxel) / time; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+                        of this same command (profiles/, `traffic_source`), only when the workload is the profiled one
+  validation            untimed: a batch of IDENTICAL garments (PointConv self-loop quirk off) must give the same WNF and mesh in the
+                        first and the last slot -- garbage in the upper slots of the benchmark batch cannot go unnoticed
+  cpu_baseline          the CPU oracle (torch-CPU port of the reference path) timed on this host for a bounded sample
 """
 import argparse
 import json
@@ -29,6 +41,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 6
 PEAK_16BIT_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / f16 (v_mfma_f32_32x32x16_*)
 SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6, "bf16x2": 3}     # matrix-core products per fp32 product (csrc/unet_split.hip)
 PEAK_HBM_GBS = 8000.0
+CLOUD_SEED = 20260928
 
 
 def parse():
@@ -36,60 +49,101 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="garments per GPU per step")
+    ap.add_argument("--workload", default="full", choices=["full", "pointnet2"],
+                    help="full = BASELINE config[2]/[4] (whole predict path); pointnet2 = config[1] (PointNet2NOCS + NOCS post-processing only)")
+    ap.add_argument("--batch", type=int, default=None, help="garments per GPU per step (default 16; 32 for --workload pointnet2)")
     ap.add_argument("--points", type=int, default=6000)
     ap.add_argument("--grid", type=int, default=128, help="feature-volume edge G (north_star: 128; reference ckpt default: 32)")
     ap.add_argument("--reduce", default="mean", choices=["mean", "max"])
     ap.add_argument("--volume-size", type=int, default=128, help="WNF query volume edge Q")
     ap.add_argument("--conv-mode", default="f16x2", choices=["f16x2", "fp32", "bf16x3", "bf16x2"],
-                    help="arithmetic of the 3x3x3 convs: f16x2 (default; fp32 operands split into two fp16 planes, fp32 accumulation, "
-                         "error vs fp64 below the fp32 kernel's), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (preview quality)")
+                    help="arithmetic of the 3x3x3 convs of the HEADLINE pass: f16x2 (default; fp32 operands split into two fp16 planes, fp32 "
+                         "accumulation), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (preview quality)")
+    ap.add_argument("--decode-mode", default="f16x2", choices=["f16x2", "fp32"], help="arithmetic of the decoder MLPs of the headline pass")
+    ap.add_argument("--no-strict-pass", action="store_true", help="skip the second timed pass in strict fp32 arithmetic")
+    ap.add_argument("--no-host-io-pass", action="store_true", help="skip the timed pass that includes H2D of the clouds / D2H of the meshes")
+    ap.add_argument("--no-validate", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-garments", type=int, default=1)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 32 if a.workload == "pointnet2" else 16
+    return a
 
 
-class ConvTimer:
-    """HIP-event brackets around every conv3d launch (on torch's current stream = the launch stream)."""
+class KernelTimer:
+    """HIP-event brackets around selected ops.* launches (on torch's current stream = the launch stream of the C ABI)."""
 
     def __init__(self):
-        self.records = []   # (kernel, flops, bytes, start_event, end_event)
+        self.records = []   # (kernel, work, bytes, start_event, end_event)
         self.enabled = False
 
-    def install(self):
-        from garmentnets_amd import ops
+    def _wrap(self, orig, describe):
         timer = self
 
-        def wrap(orig, kernel_name):
-            def timed(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
-                if not timer.enabled:
-                    return orig(src0, src1, a, d, wp, cout, relu, with_stats)
-                B, D, H, W, C0 = src0.shape
-                cin = C0 + (0 if src1 is None else src1.shape[-1])
-                tiles = -(-D // 4) * -(-H // 8) * -(-W // 8)
-                nt = 2 if (cout % 64 == 0 and tiles * (cout // 64) * B >= 1024) else 1
-                if hasattr(wp, "mode") and wp.mode != 3 and cout % 128 == 0 and cin <= 384 and tiles * (cout // 128) * B >= 512:
-                    nt = 4                                  # the 128-wide variant (same dispatch rule as gn_conv3d_gcr_split)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = orig(src0, src1, a, d, wp, cout, relu, with_stats)
-                e1.record()
-                wbytes = (wp.tensor.numel() * 2.0) if hasattr(wp, "tensor") else wp.numel() * 4.0
-                timer.records.append((kernel_name(nt, wp), 54.0 * cin * cout * B * D * H * W, (cin + cout) * 4.0 * B * D * H * W + wbytes, e0, e1))
-                return out
-            return timed
+        def timed(*a, **kw):
+            if not timer.enabled:
+                return orig(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **kw)
+            e1.record()
+            name, work, byts = describe(out, *a, **kw)
+            timer.records.append((name, work, byts, e0, e1))
+            return out
+        return timed
 
-        ops.conv3d_gcr = wrap(ops.conv3d_gcr, lambda nt, wp: f"conv3d_gcr_kernel<{nt}>")
-        ops.conv3d_gcr_split = wrap(ops.conv3d_gcr_split, lambda nt, wp: ("conv3d_split_wide_kernel<2, %s>" if nt == 4 else "conv3d_split_kernel<%d, %d, %%s, 1>" % (
-            nt, 3 if wp.mode == ops.SPLIT_BF16X3 else 2)) % ("true" if wp.mode == ops.SPLIT_F16X2 else "false"))
-        import garmentnets_amd.components.unet3d as u
-        u.ops = ops
+    def install_conv(self):
+        from garmentnets_amd import _lib, ops
+
+        def describe(out, src0, src1, a, d, wp, cout, *rest, **kw):
+            B, D, H, W, C0 = src0.shape
+            cin = C0 + (0 if src1 is None else src1.shape[-1])
+            wbytes = (wp.tensor.numel() * 2.0) if hasattr(wp, "tensor") else wp.numel() * 4.0
+            vox = float(B) * D * H * W
+            return _lib.load().gn_last_kernel().decode(), 54.0 * cin * cout * vox, (cin + cout) * 4.0 * vox + wbytes
+
+        ops.conv3d_gcr = self._wrap(ops.conv3d_gcr, describe)
+        ops.conv3d_gcr_split = self._wrap(ops.conv3d_gcr_split, describe)
+
+    def install_points(self):
+        """PointNet++ operators (config[1]): work = squared-distance evaluations for fps / ball query / kNN, FLOPs for the GEMMs"""
+        from garmentnets_amd import ops
+
+        def d_fps(out, pos, ptr, out_ptr, max_points, m_total, *r, **k):
+            B = ptr.numel() - 1
+            return "fps_kernel", float(max_points) * (m_total / max(B, 1)) * B, pos.numel() * 4.0 + m_total * 4.0
+
+        def d_ball(out, pos, ptr, centre_idx, centre_ptr, r, K=64):
+            B = ptr.numel() - 1
+            return "ball_query_kernel", float(centre_idx.numel()) * (pos.shape[0] / max(B, 1)), pos.numel() * 4.0 + centre_idx.numel() * (K + 2) * 4.0
+
+        def d_knn(out, xs, ps, ptr_s, pq, ptr_q, k, **kw):
+            B = ptr_s.numel() - 1
+            return f"knn_interp_kernel<{k}>", float(pq.shape[0]) * (ps.shape[0] / max(B, 1)), (xs.numel() + pq.shape[0] * xs.shape[1]) * 4.0
+
+        def d_lin(out, x, w, *r, **kw):
+            M, K, N = x.shape[0], (kw.get("K") or x.shape[1]), w.shape[0]
+            return "linear_kernel", 2.0 * M * K * N, (M * K + M * N + N * K) * 4.0
+
+        ops.fps = self._wrap(ops.fps, d_fps)
+        ops.ball_query = self._wrap(ops.ball_query, d_ball)
+        ops.knn_interpolate = self._wrap(ops.knn_interpolate, d_knn)
+        ops.linear = self._wrap(ops.linear, d_lin)
+        if hasattr(ops, "sa_fused"):
+            def d_sa(out, x, pos, centre_idx, nbr, pack, **kw):
+                M, K = nbr.shape
+                return "sa_fused_kernel", 2.0 * M * (K + 1) * pack.macs_per_edge, (M * (K + 1) * (pack.cin + 3) + M * pack.cout) * 4.0
+            ops.sa_fused = self._wrap(ops.sa_fused, d_sa)
+
+    def reset(self):
+        self.records = []
 
     def summary(self):
         groups = {}
-        for name, flops, byts, e0, e1 in self.records:
-            g = groups.setdefault(name, dict(flops=0.0, bytes=0.0, ms=0.0, n=0))
-            g["flops"] += flops
+        for name, work, byts, e0, e1 in self.records:
+            g = groups.setdefault(name, dict(work=0.0, bytes=0.0, ms=0.0, n=0))
+            g["work"] += work
             g["bytes"] += byts
             g["ms"] += e0.elapsed_time(e1)
             g["n"] += 1
@@ -97,14 +151,62 @@ class ConvTimer:
 
 
 def measured_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs of THIS command, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_summary.py) -- only quoted when
-    the workload is the one that was profiled."""
-    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-    if not (os.path.exists(path) and (args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode) == (16, 6000, 128, "mean", 128, "f16x2")):
-        return None
-    k = json.load(open(path))["kernels"].get(kernel)
-    return None if k is None else k["hbm_bytes"]
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs
+    of THIS command, corrected as profiles/*_fetch_calibration.txt documents; tools/pmc_summary.py) -- only quoted when the workload is
+    the one that was profiled.  -> (bytes or None, source file or None)"""
+    if (args.workload, args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode) != ("full", 16, 6000, 128, "mean", 128, "f16x2"):
+        return None, None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            k = json.load(open(path))["kernels"].get(kernel)
+            if k is not None:
+                return k["hbm_bytes"], "profiles/" + name + " (committed PMC passes of this command, not this run)"
+    return None, None
+
+
+def conv_roofline(args, groups, conv_mode):
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[key]
+    achieved = g["work"] / (g["ms"] * 1e-3) / 1e12          # algorithmic (fp32) FLOPs: 54*Cin*Cout per voxel
+    if conv_mode == "fp32":
+        peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak"
+    else:
+        n = SPLIT_PRODUCTS[conv_mode]
+        peak = PEAK_16BIT_MFMA_TFLOPS / n
+        peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} matrix-core products per algorithmic fp32 product "
+                     f"({conv_mode}); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
+    traffic, src = measured_traffic(args, key) if conv_mode == args.conv_mode else (None, None)
+    return {"bound": "mfma", "kernel": key, "kernel_label": "reported by the C ABI (gn_last_kernel) after each launch",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
+            "traffic": traffic, "traffic_source": src,
+            "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["work"] / g["n"],
+            "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
+            "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["work"] / (v["ms"] * 1e-3) / 1e12}
+                                   for k, v in groups.items()}}
+
+
+def points_roofline(groups):
+    """config[1]: per-operator rates in the units SURVEY.md 8d names (distance evaluations / s, FPS steps / s, GEMM TFLOP/s); the
+    `roofline` object proper is the dominant operator by time"""
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    per = {}
+    for k, v in groups.items():
+        sec = v["ms"] * 1e-3
+        per[k] = {"launches": v["n"], "ms": v["ms"], "work_per_s": v["work"] / sec, "algorithmic_GBs": v["bytes"] / sec / 1e9,
+                  "work_unit": "FLOP" if ("linear" in k or "sa_fused" in k) else "squared-distance evaluations"}
+    g = groups[key]
+    sec = g["ms"] * 1e-3
+    if "linear" in key or "sa_fused" in key:
+        rl = {"bound": "mfma", "kernel": key, "achieved": g["work"] / sec / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s"}
+    else:   # fps / ball query / kNN: latency- or ALU-bound scans; against the HBM roofline their compulsory traffic is negligible -- say so
+        rl = {"bound": "hbm", "kernel": key, "achieved": g["bytes"] / sec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "note": "serial / ALU-bound scan (fps: one dependent arg-max per sample); the algorithmic bytes are tiny by nature, the operator "
+                      "rate is in per_operator.work_per_s"}
+    rl["frac"] = rl["achieved"] / rl["peak"]
+    rl.update(traffic=None, launches=g["n"], avg_launch_ms=g["ms"] / g["n"], per_operator=per)
+    return rl
 
 
 def cpu_baseline(args, hp, sd):
@@ -129,15 +231,60 @@ def cpu_baseline(args, hp, sd):
             best, cores = dtp, nt
     torch.set_num_threads(cores)
     n = args.cpu_baseline_garments
-    x, pos, batch = S.synthetic_cloud(n, args.points, seed=12345)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
-    t0 = time.time()
-    P.predict(sd_cpu, hp, x, pos, batch, Q=args.volume_size, level=0.5, sigma=0.5, auto_level=True)
-    dt = time.time() - t0
+    if args.workload == "pointnet2":
+        n = max(n, 4)
+        x, pos, batch = S.synthetic_cloud(n, args.points, seed=12345)
+        with torch.no_grad():
+            P.pointnet2_forward(sd_cpu, hp, x[:args.points], pos[:args.points], batch[:args.points])
+            t0 = time.time()
+            P.pointnet2_forward(sd_cpu, hp, x, pos, batch)
+            dt = time.time() - t0
+        what = f"{n} garments, PointNet2NOCS forward + NOCS post-processing (N={args.points})"
+    else:
+        x, pos, batch = S.synthetic_cloud(n, args.points, seed=12345)
+        t0 = time.time()
+        P.predict(sd_cpu, hp, x, pos, batch, Q=args.volume_size, level=0.5, sigma=0.5, auto_level=True)
+        dt = time.time() - t0
+        what = f"{n} garment(s) of the same workload (N={args.points}, G={args.grid} {args.reduce}, Q={args.volume_size})"
     return {"value": n / dt, "unit": "garments/s", "cores": cores, "kind": "port",
-            "sample": f"{n} garment(s) of the same workload (N={args.points}, G={args.grid} {args.reduce}, Q={args.volume_size}), "
-                      f"oracle/pipeline.py on torch-CPU fp32 with {cores} of {ncpu} hardware threads (fastest of a short sweep; GGM / marching cubes "
-                      f"single-threaded C as in the reference), {dt:.1f} s"}
+            "sample": f"{what}, oracle/pipeline.py on torch-CPU fp32 with {cores} of {ncpu} hardware threads (fastest of a short sweep; fps / ball "
+                      f"query / kNN / GGM / marching cubes single-threaded C as in the reference), {dt:.1f} s"}
+
+
+def validate(model, args, dev, auto_level):
+    """untimed: `batch` IDENTICAL garments with the PointConv self-loop quirk off (it links centre i to point i of the whole batch, so a
+    garment's result legitimately depends on its slot otherwise) -- slot 0 and slot B-1 must agree"""
+    from garmentnets_amd import synthetic as S
+    from garmentnets_amd.batch import Batch
+    from garmentnets_amd.predict import predict_batch
+    B, n = args.batch, args.points
+    pn = model.pointnet2_nocs
+    saved = (pn.sa1_module.conv.add_self_loops, pn.sa2_module.conv.add_self_loops)
+    pn.sa1_module.conv.add_self_loops = pn.sa2_module.conv.add_self_loops = False
+    try:
+        x, pos, _ = S.synthetic_cloud(1, n, seed=4242)
+        data = Batch(sizes=[n] * B, x=x.repeat(B, 1), pos=pos.repeat(B, 1), batch=torch.arange(B).repeat_interleave(n)).to(dev)
+        if args.workload == "pointnet2":
+            with torch.no_grad():
+                p2 = model.pointnet2_forward(data)
+            lg = p2["per_point_logits"]
+            same = bool(torch.equal(lg[:n], lg[(B - 1) * n:])) and bool(torch.equal(p2["global_feature"][0], p2["global_feature"][B - 1]))
+            out = {"identical_garments": B, "logits_and_global_feature_slot0_eq_slotlast": same}
+            ok = same
+        else:
+            res = predict_batch(model, data, volume_size=args.volume_size, iso_surface_level=0.5, gradient_sigma=0.5, auto_level=auto_level)
+            w0, w1 = res[0]["wnf_volume"], res[B - 1]["wnf_volume"]
+            spread = float((w0 - w1).abs().max())
+            faces_equal = res[0]["faces"].shape == res[B - 1]["faces"].shape and bool(torch.equal(res[0]["faces"], res[B - 1]["faces"]))
+            dv = float((res[0]["verts"] - res[B - 1]["verts"]).abs().max()) if faces_equal else None
+            out = {"identical_garments": B, "wnf_max_abs_diff_slot0_vs_slotlast": spread, "faces_equal": faces_equal, "verts_max_abs_diff": dv,
+                   "verts": int(res[0]["verts"].shape[0]), "wnf_checksum_slot0": float(w0.double().sum()), "wnf_checksum_slotlast": float(w1.double().sum())}
+            ok = spread <= 1e-5 and bool(torch.isfinite(w1).all()) and (faces_equal or spread > 0)
+        out["ok"] = bool(ok)
+        return out
+    finally:
+        pn.sa1_module.conv.add_self_loops, pn.sa2_module.conv.add_self_loops = saved
 
 
 def main():
@@ -150,53 +297,97 @@ def main():
     dev = torch.device("cuda", local_rank)
     parallel.init(backend="nccl", device=dev)      # "nccl" is RCCL on ROCm; no-op for one process
 
-    from garmentnets_amd import synthetic as S
+    from garmentnets_amd import ops, synthetic as S
     from garmentnets_amd.batch import Batch
     from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
-    from garmentnets_amd.predict import predict_batch
+    from garmentnets_amd.predict import predict_batch, to_host
 
     hp = S.default_hparams(grid=args.grid, reduce_method=args.reduce)
     sd = S.synthetic_state_dict(hp, 0)
     model = ConvImplicitWNFPipeline(**hp)
     model.load_state_dict(sd)
     model = model.to(dev).eval().requires_grad_(False)
-    x, pos, batch = S.synthetic_cloud(args.batch, args.points, seed=1000 * rank)
-    data = Batch(sizes=[args.points] * args.batch, x=x, pos=pos, batch=batch).to(dev)   # resident in HBM before timing
-    timer = ConvTimer()
-    timer.install()
-    from garmentnets_amd import ops as _ops
-    _ops.CONV_MODE = _ops.CONV_MODE_NAMES[args.conv_mode]
+    # the global batch of batch x world garments (one seed), sharded contiguously: this rank owns garments [lo, hi)
+    global_batch = args.batch * world
+    lo, hi = parallel.shard_range(global_batch, rank, world)
+    x, pos, batch = S.synthetic_cloud(hi - lo, args.points, seed=CLOUD_SEED, first=lo)
+    host_data = Batch(sizes=[args.points] * (hi - lo), x=x.pin_memory(), pos=pos.pin_memory(), batch=batch.pin_memory())
+    data = host_data.to(dev)                         # resident in HBM before timing
+    timer = KernelTimer()
+    if args.workload == "pointnet2":
+        timer.install_points()
+    else:
+        timer.install_conv()
+    import garmentnets_amd.components.unet3d as u
+    u.ops = ops
 
-    def step():
-        return predict_batch(model, data, volume_size=args.volume_size, iso_surface_level=0.5, gradient_sigma=0.5,
-                             gradient_direction="ascent", auto_level=auto_level)
+    auto_level = [False]
 
+    def step(d=data):
+        if args.workload == "pointnet2":
+            with torch.no_grad():
+                return model.pointnet2_forward(d)
+        return predict_batch(model, d, volume_size=args.volume_size, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
+                             auto_level=auto_level[0])
+
+    def step_host_io():
+        res = step(host_data.to(dev, non_blocking=True))
+        if args.workload == "pointnet2":
+            return {k: v.cpu() for k, v in res.items() if torch.is_tensor(v)}
+        return [to_host(r) for r in res]
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        timer.reset()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = fn()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        return dt, res, timer.summary()
+
+    def set_modes(conv, decode):
+        ops.CONV_MODE = ops.CONV_MODE_NAMES[conv]
+        ops.DECODE_MODE = decode
+
+    set_modes(args.conv_mode, args.decode_mode)
     # synthetic weights: use the reference's fixed level 0.5 if every garment's WNF straddles it, else the mid level
-    auto_level = False
-    probe = step()
-    if any(bool(torch.isnan(r["verts"]).any()) for r in probe):
-        auto_level = True
-    verts_total = 0
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    verts_total = sum(int(r["verts"].shape[0]) for r in res)
-    assert not any(bool(torch.isnan(r["verts"]).any()) for r in res), "marching cubes produced a placeholder mesh"
+    if args.workload == "full":
+        probe = step()
+        if any(bool(torch.isnan(r["verts"]).any()) for r in probe):
+            auto_level[0] = True
+        del probe
+    dt, res, groups = timed(step, args.steps, max(0, args.warmup - (1 if args.workload == "full" else 0)))
+    verts_total = None
+    if args.workload == "full":
+        verts_total = sum(int(r["verts"].shape[0]) for r in res)
+        assert not any(bool(torch.isnan(r["verts"]).any()) for r in res), "marching cubes produced a placeholder mesh"
+    del res
+
+    strict = None
+    if not args.no_strict_pass and (args.conv_mode, args.decode_mode) != ("fp32", "fp32") and args.workload == "full":
+        set_modes("fp32", "fp32")
+        dt_s, res_s, groups_s = timed(step, args.steps, 1)
+        del res_s
+        strict = (dt_s, groups_s)
+        set_modes(args.conv_mode, args.decode_mode)
+    hostio = None
+    if not args.no_host_io_pass:
+        dt_h, res_h, _ = timed(step_host_io, args.steps, 1)
+        del res_h
+        hostio = dt_h
 
     # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods
     stages_ms = None
-    if rank == 0:
+    if rank == 0 and args.workload == "full":
         from garmentnets_amd.common import marching_cubes_util as mcu
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         with torch.no_grad():
@@ -208,7 +399,7 @@ def main():
             wnf_all = model.volume_lattice_forward(u3, args.volume_size)["pred_volume"]
             ev[3].record()
             lvl = 0.5
-            if auto_level:
+            if auto_level[0]:
                 mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
                 lvl = 0.5 * (float(mm[0]) + float(mm[1]))
             for b_, mesh in enumerate(mcu.wnf_batch_to_meshes_gpu(wnf_all, lvl, 0.5, "ascent")):
@@ -218,48 +409,66 @@ def main():
         torch.cuda.synchronize()
         names = ("pointnet2_forward", "unet3d_forward (gridding + UNet)", "volume_lattice_forward (sampler + decoder)", "GGM + MC33 + surface decode")
         stages_ms = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
+        del p2, u3, wnf_all
 
-    # the only collective: per-rank (garments, seconds) over RCCL/xGMI
-    per_rank = parallel.gather_metrics([args.batch * args.steps, dt], device=dev)
+    validation = None
+    if rank == 0 and not args.no_validate:
+        validation = validate(model, args, dev, auto_level[0])
+
+    # the only collective: per-rank (garments, seconds of each timed pass) over RCCL/xGMI
+    n_local = (hi - lo) * args.steps
+    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0], device=dev)
     if rank == 0:
         value, tmax = parallel.aggregate_throughput(per_rank)
-        garments = args.batch * world * args.steps
-        groups = timer.summary()
-        key = max(groups, key=lambda k: groups[k]["ms"])
-        g = groups[key]
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12          # algorithmic (fp32) FLOPs: 54*Cin*Cout per voxel
-        if args.conv_mode == "fp32":
-            peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak"
+        garments = sum(r[0] for r in per_rank)
+        assert garments == global_batch * args.steps
+        split = args.conv_mode != "fp32"
+        dtype = "f32" if not split and args.decode_mode == "fp32" else (
+            f"f32 ({args.conv_mode} operand split on the 16-bit matrix cores for the 3x3x3 convs" + (" and the decoder MLPs" if args.decode_mode == "f16x2" else "") +
+            ", fp32 accumulation; everything else fp32/fp64)" if split else "f32 (f16x2 operand split for the decoder MLPs only)")
+        if args.workload == "pointnet2":
+            metric = "garments/s PointNet++ NOCS forward (pointnet2_nocs.py:134-166 + NOCS post-processing)"
+            workload = f"PointNet2NOCS forward only, batch={args.batch}/GPU, {args.points}-pt clouds (BASELINE config[1])"
+            dtype = "f32"
+            roofline = points_roofline(groups)
         else:
-            n = SPLIT_PRODUCTS[args.conv_mode]
-            peak = PEAK_16BIT_MFMA_TFLOPS / n
-            peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} matrix-core products per algorithmic fp32 product "
-                         f"({args.conv_mode}); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
+            metric = "garments/s end-to-end predict (PointNet++ -> gridding -> UNet3D -> WNF decode -> marching cubes)"
+            workload = (f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, {args.grid}^3 feature volume ({args.reduce}), "
+                        f"{args.volume_size}^3 WNF + GGM + MC33 + surface decode")
+            roofline = conv_roofline(args, groups, args.conv_mode)
         line = {
-            "metric": "garments/s end-to-end predict (PointNet++ -> gridding -> UNet3D -> WNF decode -> marching cubes)",
-            "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_mode == "fp32" else f"f32 ({args.conv_mode} operand split on the 16-bit matrix cores for the 3x3x3 convs, fp32 accumulation; everything else fp32/fp64)",
-            "data": "synthetic",
-            "config": {"workload": f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, "
-                                   f"{args.grid}^3 feature volume ({args.reduce}), {args.volume_size}^3 WNF + GGM + MC33 + surface decode",
-                       "batch_per_gpu": args.batch, "points": args.points, "grid": args.grid, "reduce": args.reduce,
-                       "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level else 0.5,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "batch_per_gpu": args.batch, "global_batch": global_batch,
+                       "sharding": f"garments [r*{args.batch}, (r+1)*{args.batch}) of one seeded global batch per rank (parallel.shard_range)",
+                       "points": args.points, "grid": args.grid, "reduce": args.reduce,
+                       "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level[0] else 0.5,
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
+            "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh)",
+            "rccl_ranks_seen": len(per_rank),
             "stages_ms": stages_ms,
-            "roofline": {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "peak_note": peak_note,
-                         "traffic": measured_traffic(args, key),
-                         "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["flops"] / g["n"],
-                         "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
-                         "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
-                                                for k, v in groups.items()}},
+            "roofline": roofline,
         }
+        if strict:
+            ts = max(r[2] for r in per_rank)
+            line["strict_fp32"] = {"value": garments / ts, "unit": "garments/s", "ms_per_step": 1e3 * ts / args.steps, "steps": args.steps,
+                                   "dtype": "f32 (v_mfma_f32_32x32x2_f32 convs + fp32 decoder MLPs: --conv-mode fp32 --decode-mode fp32)",
+                                   "roofline": conv_roofline(args, strict[1], "fp32")}
+        if hostio:
+            th = max(r[3] for r in per_rank)
+            line["with_host_io"] = {"value": garments / th, "unit": "garments/s", "ms_per_step": 1e3 * th / args.steps, "steps": args.steps,
+                                    "includes": "pinned-host -> HBM copy of the clouds, the step, device -> host copy of verts / faces / normals / values / "
+                                                "gradient magnitude / warp field of every garment (predict.to_host)" if args.workload == "full" else
+                                                "pinned-host -> HBM copy of the clouds, the step, device -> host copy of every result tensor"}
+        if validation is not None:
+            line["validation"] = validation
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, hp, sd)
         print(json.dumps(line))
+        if validation is not None and not validation["ok"]:
+            raise SystemExit("bench.py: validation failed (identical garments gave different results in slot 0 and the last slot)")
     if world > 1:
         torch.distributed.destroy_process_group()
 

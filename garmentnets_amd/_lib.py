@@ -28,11 +28,12 @@ PROTOTYPES = {
     "gn_linear": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
     "gn_nocs_head": [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_features": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
-    "gn_grid_scatter": [_vp, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp],
+    "gn_grid_scatter_workspace_bytes": [_i64, _i32, _i32],
+    "gn_grid_scatter": [_vp, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "gn_channel_stats": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
-    "gn_groupnorm_affine": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp],
+    "gn_groupnorm_affine": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_conv3d_gcr": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
-    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_stats": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_trilinear_sample": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i32, _vp],
@@ -47,7 +48,7 @@ PROTOTYPES = {
     "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
-_RESTYPES = {"gn_mc33_workspace_bytes": _sz}
+_RESTYPES = {"gn_mc33_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz}
 
 _lib = None
 
@@ -68,6 +69,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.gn_last_error.restype = ctypes.c_char_p
     lib.gn_last_error.argtypes = []
+    lib.gn_last_kernel.restype = ctypes.c_char_p
+    lib.gn_last_kernel.argtypes = []
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes

@@ -89,14 +89,22 @@ class _IsoGraph:
 
 
 _ISO_GRAPHS = {}
+
+
+def clear_iso_graphs():
+    """drop the cached per-slot graphs and their static buffers (about 5 volumes of Q^3 floats + the MC33 workspace each)"""
+    _ISO_GRAPHS.clear()
+
+
 USE_ISO_GRAPHS = True      # wnf_batch_to_meshes_gpu replays a captured graph per garment slot (False: plain launches)
 
 
 def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
     """wnf_to_mesh_gpu for a whole (B,Q,Q,Q) batch with ONE host synchronisation: the per-garment kernels (GGM, min/max, MC33 with a
-    generous vertex capacity; one HIP-graph replay per garment slot: the returned tensors are views of that slot's static buffers and
-    are overwritten by the next call with the same slot) are all queued first, the B (min, max, #verts, #faces) records come back in a single copy, then the
-    per-garment tails (slicing, vertex look-ups) are queued.  Same results and the same error contract as the one-garment function:
+    generous vertex capacity; one HIP-graph replay per garment slot) are all queued first, the B (min, max, #verts, #faces) records come back in a single copy, then the
+    per-garment tails (slicing, vertex look-ups) are queued.  Every returned tensor is the caller's own (copied out of the slot buffers)
+    except 'ggm', the (Q,Q,Q) gradient-magnitude volume, which stays a view of slot b's buffer until the next call with the same
+    (slot, Q, level, sigma) -- clone it to keep it.  Same results and the same error contract as the one-garment function:
     -> list of B entries, each a mesh dict or the exception (ValueError / RuntimeError) scikit-image would have raised."""
     if gradient_direction not in ("ascent", "descent"):
         raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % gradient_direction)
@@ -139,6 +147,8 @@ def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_
             out.append(RuntimeError("No surface found at the given iso value."))
             continue
         verts_vox, faces, normals, values = mcs[b][0][:nv], mcs[b][1][:nf], mcs[b][2][:nv], mcs[b][3][:nv]
+        if USE_ISO_GRAPHS:       # slot b's static buffers are overwritten by the next replay: hand out copies (a few MB per garment)
+            faces, normals, values = faces.clone(), normals.clone(), values.clone()
         if gradient_direction == "descent":
             faces = torch.flip(faces, dims=[1])
         out.append(dict(verts=verts_vox.double() * spacing, verts_f32=ops.scale_verts(verts_vox, spacing), faces=faces, normals=normals,

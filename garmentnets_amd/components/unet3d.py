@@ -46,16 +46,19 @@ class SingleConv(PackedModule, nn.Sequential):
         st1 = None
         if src1 is not None:
             st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
-        a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
         if ops.CONV_MODE != ops.CONV_FP32:      # split-operand path on the 16-bit matrix cores (csrc/unet_split.hip)
             mode = ops.CONV_MODE
+            # fp16 planes: the sample's activations are range-normalised by a power of two (exact, undone in the epilogue)
+            a, d, act_inv = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta, with_act_scale=True) \
+                if mode == ops.SPLIT_F16X2 else ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta) + (None,)
             cache = self.__dict__.setdefault("_split_packs", {})
             key = (mode, self.conv.weight.device, self.conv.weight._version)
             if key not in cache:
                 cache.clear()
                 cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
-            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], self.conv.out_channels, relu=True, with_stats=with_stats)
+            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], self.conv.out_channels, relu=True, with_stats=with_stats, act_inv=act_inv)
             return r if with_stats else (r, None)
+        a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
         if with_stats:
             return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True, with_stats=True)
         return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True), None

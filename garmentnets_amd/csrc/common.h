@@ -36,7 +36,12 @@ void gn_set_error(const char *fmt, ...);
         }                                                                            \
     } while (0)
 
-static inline hipStream_t gn_stream(void *s) { return (hipStream_t)s; }
+// the launch stream of a C-ABI call.  A non-null stream also selects the device: kernels, memsets and function attributes of this
+// call go to the device the stream lives on (hipSetDevice when it differs from the thread's current one), so a caller working on
+// cuda:N only has to pass a stream of that device (ops._stream takes it from the tensors).  The null stream means "current device".
+hipStream_t gn_stream(void *s);
+// name of the kernel variant the last gn_conv3d_* call of this thread launched (bench.py labels its roofline with it)
+void gn_note_kernel(const char *name);
 static inline int64_t gn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // squared distance in the pinned operation order ((dx*dx + dy*dy) + dz*dz), fp32, no FMA contraction

@@ -4,8 +4,17 @@
 // y = bn(relu(x W^T + b)) three times, on PRE-SAMPLED feature rows; the BatchNorm affine of a hidden layer is folded into the
 // NEXT layer's weights and bias on the host (W' = W diag(s), b' = b + W t: exact algebra, evaluated in fp64).  Arithmetic as in unet_split.hip's f16x2 mode: every fp32
 // operand is split into two fp16 planes (x = x1 + x2, residual <= 2^-22 |x|), three MFMA products per fp32 product
-// (x1w2 + x2w1 + x1w1, v_mfma_f32_32x32x16_f16, fp32 accumulation); the weights carry a power-of-two scale per layer (max |w| in
-// [1, 2)) that the epilogue undoes exactly.
+// (x1w2 + x2w1 + x1w1, v_mfma_f32_32x32x16_f16, fp32 accumulation).
+//
+// Range (block floating point, all scales exact powers of two): the decoder's input is the UN-normalised ReLU output of the UNet's
+// last convolution, so nothing bounds it a priori.  (a) The rows are multiplied by s_x, chosen on the device per garment from the
+// statistics the last conv's epilogue already produced (largest per-channel rms -> [1, 2): gn_decoder_input_scale), the biases by
+// the same s_x (ReLU is positively homogeneous, so the whole chain computes s_x times the true values) and the output sum by 1/s_x.
+// (b) Every hidden unit carries its own static scale: weight rows are scaled so that the row maximum is in [1, 2) and the inverse
+// is folded into the NEXT layer's columns on the host, so hidden activations are split in units where they are O(1..10) whatever
+// the checkpoint's weight magnitudes (heavy-tailed rows included).  What is left -- a hidden value beyond 65504 in those units --
+// turns into inf - inf = NaN in the accumulators and reaches the output as NaN (gn_relu propagates it): predict_batch checks for
+// that and re-runs the batch with the fp32 kernels.
 //
 // Structure (nothing in common with the fp32 kernel):
 //  * TRANSPOSED chain, activations never leave the registers.  A wave owns 32 queries and computes H^T[units][32 q] =
@@ -36,8 +45,8 @@ typedef float f32x2q __attribute__((ext_vector_type(2)));
 struct DecSplitArgs {
     const float *xin; int ldxin; long long M;
     const unsigned char *wp;         // [stages][4 k-group steps][2 blocks][2 planes][64 lanes] x 16 B; step order: layer 1 (pair, k-group), layer 2
-    const float *tab;                // tab1 [8][2][16] (b1) | tab2 [8][2][1+OUT][16] (b2', w3') | b3', s3, t3 [3][OUT]
-    float inv1, inv2;                // exact powers of two undoing the weight scales
+    const float *tab;                // tab1 [8][2][16] (b1'') | tab2 [8][2][1+OUT][16] (b2'', w3'') | b3', s3, t3 [3][OUT]
+    const float *xscale;             // NULL or device {s_x, 1 / s_x}: the garment's input scale (exact power of two)
     float *out; int ldo;
 };
 
@@ -94,7 +103,12 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
 
-    for (int i = tid; i < TABN; i += 256) tab[i] = p.tab[i];
+    const float sx = p.xscale ? p.xscale[0] : 1.f, inv_sx = p.xscale ? p.xscale[1] : 1.f;
+    // the bias entries (all of tab1, row 0 of every tab2 block) enter in the scaled units of the chain
+    for (int i = tid; i < TABN; i += 256) {
+        const bool bias = i < TAB1 || (i < TAB1 + TAB2 && ((i - TAB1) / 16) % (1 + OUTC) == 0);
+        tab[i] = bias ? __fmul_rn(p.tab[i], sx) : p.tab[i];
+    }
 
     // each wave DMAs 4 of a stage's 16 fragments.  Stage s of tile n sits in ring slot (n * NSTAGE + s) % 4: `sb` carries n * NSTAGE
     const unsigned char *wsrc = p.wp + (wave * 4) * 1024;   // wave-uniform (SGPRs); the lane adds 16 * lane
@@ -129,10 +143,10 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
         uint4 x0[2][K0G], h1[2][16];
 #pragma unroll
         for (int g = 0; g < K0G; ++g) {
-            ds_split2(raw[2 * g].x, raw[2 * g].y, x0[0][g].x, x0[1][g].x);
-            ds_split2(raw[2 * g].z, raw[2 * g].w, x0[0][g].y, x0[1][g].y);
-            ds_split2(raw[2 * g + 1].x, raw[2 * g + 1].y, x0[0][g].z, x0[1][g].z);
-            ds_split2(raw[2 * g + 1].z, raw[2 * g + 1].w, x0[0][g].w, x0[1][g].w);
+            ds_split2(__fmul_rn(raw[2 * g].x, sx), __fmul_rn(raw[2 * g].y, sx), x0[0][g].x, x0[1][g].x);
+            ds_split2(__fmul_rn(raw[2 * g].z, sx), __fmul_rn(raw[2 * g].w, sx), x0[0][g].y, x0[1][g].y);
+            ds_split2(__fmul_rn(raw[2 * g + 1].x, sx), __fmul_rn(raw[2 * g + 1].y, sx), x0[0][g].z, x0[1][g].z);
+            ds_split2(__fmul_rn(raw[2 * g + 1].z, sx), __fmul_rn(raw[2 * g + 1].w, sx), x0[0][g].w, x0[1][g].w);
         }
         float psum[OUTC];
 #pragma unroll
@@ -148,10 +162,10 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
                 if (P < 4) {
                     const int nb = 2 * P + blk;
                     const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
-                    const float v0 = gn_relu(fmaf(acc[set][blk][4 * qd + 0], p.inv1, bv.x));
-                    const float v1 = gn_relu(fmaf(acc[set][blk][4 * qd + 1], p.inv1, bv.y));
-                    const float v2 = gn_relu(fmaf(acc[set][blk][4 * qd + 2], p.inv1, bv.z));
-                    const float v3 = gn_relu(fmaf(acc[set][blk][4 * qd + 3], p.inv1, bv.w));
+                    const float v0 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 0], bv.x));
+                    const float v1 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 1], bv.y));
+                    const float v2 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 2], bv.z));
+                    const float v3 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 3], bv.w));
                     // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; a register quad fills half a fragment
                     const int g2 = 2 * nb + (qd >> 1);
                     if (qd & 1) {
@@ -165,10 +179,10 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
                     const int nb = 2 * (P - 4) + blk;
                     const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
                     const float4 bv = *reinterpret_cast<const float4 *>(tb);
-                    const float v0 = gn_relu(fmaf(acc[set][blk][4 * qd + 0], p.inv2, bv.x));
-                    const float v1 = gn_relu(fmaf(acc[set][blk][4 * qd + 1], p.inv2, bv.y));
-                    const float v2 = gn_relu(fmaf(acc[set][blk][4 * qd + 2], p.inv2, bv.z));
-                    const float v3 = gn_relu(fmaf(acc[set][blk][4 * qd + 3], p.inv2, bv.w));
+                    const float v0 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 0], bv.x));
+                    const float v1 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 1], bv.y));
+                    const float v2 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 2], bv.z));
+                    const float v3 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 3], bv.w));
 #pragma unroll
                     for (int o = 0; o < OUTC; ++o) {
                         const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
             const float s = psum[o] + __shfl_xor(psum[o], 32);
             if (h == 0 && m < p.M) {
                 const float *t3 = tab + TAB1 + TAB2;
-                float y = gn_relu(__fadd_rn(s, t3[o]));
+                float y = gn_relu(__fadd_rn(__fmul_rn(s, inv_sx), t3[o]));
                 y = __fadd_rn(__fmul_rn(y, t3[OUTC + o]), t3[2 * OUTC + o]);
                 p.out[m * p.ldo + o] = y;
             }
@@ -273,16 +287,46 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
 // (they had four stages = 24 x 4 MFMAs to arrive).  The wrap-around (stage (t+4) % NSTAGE belongs to the NEXT tile; the last tile
 // fetches four stages it never uses) keeps every count independent of the tile.
 
-extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, float inv1, float inv2,
+// the garment's input scale from the per-channel sums of squares of the volume the rows are sampled from (= the statistics the last
+// conv's epilogue emitted): s = 2^k with (largest channel rms) * s in [1, 2), clamped to smax (the pack's bound that keeps the scaled
+// biases small); out[b] = {s, 1/s}
+__global__ void decoder_input_scale_kernel(const double *__restrict__ sumsq, int64_t V, int B, int C, float smax, float *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double m2 = 0.0;
+    for (int c = 0; c < C; ++c) { const double v = sumsq[(int64_t)b * C + c]; if (v > m2) m2 = v; }
+    const float m = (float)sqrt(m2 / (double)V);
+    float s = 1.f;
+    if (m > 0.f && m < INFINITY) {
+        int e = 0;
+        (void)frexpf(m, &e);
+        e = 1 - e;
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+        s = ldexpf(1.f, e);
+    }
+    if (s > smax) s = smax;
+    out[2 * b] = s;
+    out[2 * b + 1] = 1.f / s;
+}
+
+extern "C" int gn_decoder_input_scale(const double *sumsq, int64_t V, int B, int C, float smax, float *out2, void *stream) {
+    GN_REQUIRE(B >= 0 && C > 0 && V > 0 && smax > 0.f, "gn_decoder_input_scale: bad sizes");
+    if (B == 0) return GN_OK;
+    hipLaunchKernelGGL(decoder_input_scale_kernel, dim3((unsigned)gn_cdiv(B, 64)), dim3(64), 0, gn_stream(stream), sumsq, V, B, C, smax, out2);
+    GN_LAUNCH_CHECK("gn_decoder_input_scale");
+    return GN_OK;
+}
+
+extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                                         int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
     GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
     GN_REQUIRE((C0 == 128 || C0 == 32) && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_split: only [128 | 32, 256, 256, out] decoders are packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
     GN_REQUIRE(ldxin >= C0 && ldxin % 4 == 0, "gn_implicit_decode_split: rows need a 16-byte aligned leading dimension");
-    GN_REQUIRE(inv1 > 0.f && inv2 > 0.f, "gn_implicit_decode_split: bad weight scales");
     if (M == 0) return GN_OK;
     GN_REQUIRE(xin && wpack && tab && out, "gn_implicit_decode_split: null pointer");
     DecSplitArgs p;
-    p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.inv1 = inv1; p.inv2 = inv2; p.out = out; p.ldo = ldo;
+    p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.xscale = xscale; p.out = out; p.ldo = ldo;
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
     const int64_t slots = (C0 == 32 && OUT == 1) ? 512 : 256;                       // persistent workgroups: two per CU when they fit (K0G = 2), else one
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);

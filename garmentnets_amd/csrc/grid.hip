@@ -75,26 +75,21 @@ __device__ __forceinline__ float dec_f32(unsigned e) {
     return __uint_as_float(u);
 }
 
-template <int REDUCE>  // 0 max, 1 mean
-__global__ __launch_bounds__(256) void scatter_accum_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ flat_idx,
-                                                            int64_t N, int C, float *__restrict__ vol, int32_t *__restrict__ count) {
+// max: order-independent by construction (atomicMax on the encoding).
+__global__ __launch_bounds__(256) void scatter_max_accum_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ flat_idx,
+                                                                int64_t N, int C, float *__restrict__ vol, int32_t *__restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= N) return;
     const int64_t cell = flat_idx[p];
     if (lane == 0) atomicAdd(&count[cell], 1);
     float *v = vol + cell * C;
-    for (int ch = lane; ch < C; ch += 64) {
-        float x = src[p * lds + ch];
-        if (REDUCE == 0) atomicMax(reinterpret_cast<unsigned *>(v) + ch, enc_f32(x));
-        else atomicAdd(v + ch, x);
-    }
+    for (int ch = lane; ch < C; ch += 64) atomicMax(reinterpret_cast<unsigned *>(v) + ch, enc_f32(src[p * lds + ch]));
 }
 
-// the first point that reaches a cell here finalises it (decode the max / divide the sum by the count)
-template <int REDUCE>
-__global__ __launch_bounds__(256) void scatter_finalize_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int C,
-                                                               float *__restrict__ vol, int32_t *__restrict__ count) {
+// the first point that reaches a cell here finalises it (decode the max)
+__global__ __launch_bounds__(256) void scatter_max_finalize_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int C,
+                                                                   float *__restrict__ vol, int32_t *__restrict__ count) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= N) return;
@@ -104,26 +99,77 @@ __global__ __launch_bounds__(256) void scatter_finalize_kernel(const int32_t *__
     c = __shfl(c, 0);
     if (c <= 0) return;
     float *v = vol + cell * C;
-    for (int ch = lane; ch < C; ch += 64) {
-        if (REDUCE == 0) v[ch] = dec_f32(__float_as_uint(v[ch]));
-        else v[ch] = __fdiv_rn(v[ch], (float)c);
-    }
+    for (int ch = lane; ch < C; ch += 64) v[ch] = dec_f32(__float_as_uint(v[ch]));
+}
+
+// mean: DETERMINISTIC.  A float atomicAdd into the volume would make the sum depend on the arrival order of a cell's points (with
+// seeded synthetic weights a cell collects > 1000 points; the run-to-run spread, amplified by the GroupNorm of a > 99 % empty
+// volume, reached 4e-5 on the WNF).  Instead every occupied cell gets an OWNER point (first atomicCAS on the zeroed count
+// workspace; which point wins only decides where the partial sums live), the cell's points add their channels into the owner's
+// row of an fp64 scratch [N][C] with fp64 atomics -- sums of <= 2^13 fp32 values are exact in fp64 unless their exponents span
+// more than 2^16, so the result does not depend on the order -- and the owner stores fp32(sum) / count: for one or two points
+// per cell (the realistic case: 6000 points over 128^3 cells) bit-identical to a sequential fp32 sum, closer to the exact mean
+// than it otherwise.
+__global__ __launch_bounds__(256) void scatter_mean_owner_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int32_t *__restrict__ count,
+                                                                 int32_t *__restrict__ owner_of, int32_t *__restrict__ npts) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int64_t cell = flat_idx[p];
+    const int old = atomicCAS(&count[cell], 0, (int)p + 1);
+    const int owner = old == 0 ? (int)p : old - 1;
+    owner_of[p] = owner;
+    atomicAdd(&npts[owner], 1);
+}
+
+__global__ __launch_bounds__(256) void scatter_mean_accum_kernel(const float *__restrict__ src, int lds, int64_t N, int C,
+                                                                 const int32_t *__restrict__ owner_of, double *__restrict__ acc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= N) return;
+    double *a = acc + (int64_t)owner_of[p] * C;
+    for (int ch = lane; ch < C; ch += 64) atomicAdd(a + ch, (double)src[p * lds + ch]);
+}
+
+__global__ __launch_bounds__(256) void scatter_mean_finalize_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int C,
+                                                                    const int32_t *__restrict__ owner_of, const int32_t *__restrict__ npts,
+                                                                    const double *__restrict__ acc, float *__restrict__ vol,
+                                                                    int32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= N || owner_of[p] != (int)p) return;
+    const int64_t cell = flat_idx[p];
+    const float c = (float)npts[p];
+    float *v = vol + cell * C;
+    for (int ch = lane; ch < C; ch += 64) v[ch] = __fdiv_rn((float)acc[p * C + ch], c);
+    if (lane == 0) count[cell] = 0;                 // gn_grid_stats expects the count workspace zeroed
+}
+
+extern "C" size_t gn_grid_scatter_workspace_bytes(int64_t N, int C, int reduce) {
+    if (reduce != 1 || N <= 0) return 0;
+    return (size_t)N * C * sizeof(double) + 2 * (size_t)N * sizeof(int32_t);
 }
 
 extern "C" int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
-                               float *vol, int32_t *count_ws, void *stream) {
+                               float *vol, int32_t *count_ws, void *ws, size_t ws_bytes, void *stream) {
     GN_REQUIRE(N >= 0 && C > 0 && cells >= 0 && (reduce == 0 || reduce == 1), "gn_grid_scatter: bad arguments");
+    GN_REQUIRE(N < (int64_t)0x7fffffff, "gn_grid_scatter: more than 2^31-2 points");
+    GN_REQUIRE(ws_bytes >= gn_grid_scatter_workspace_bytes(N, C, reduce) && (ws || !gn_grid_scatter_workspace_bytes(N, C, reduce)),
+               "gn_grid_scatter: workspace too small (gn_grid_scatter_workspace_bytes)");
     hipStream_t st = gn_stream(stream);
     GN_HIP(hipMemsetAsync(vol, 0, sizeof(float) * (size_t)cells * C, st), "gn_grid_scatter(memset vol)");
     GN_HIP(hipMemsetAsync(count_ws, 0, sizeof(int32_t) * (size_t)cells, st), "gn_grid_scatter(memset count)");
     if (N == 0) return GN_OK;
     dim3 grid((unsigned)gn_cdiv(N, 4)), block(256);
     if (reduce == 0) {
-        hipLaunchKernelGGL(scatter_accum_kernel<0>, grid, block, 0, st, src, lds, flat_idx, N, C, vol, count_ws);
-        hipLaunchKernelGGL(scatter_finalize_kernel<0>, grid, block, 0, st, flat_idx, N, C, vol, count_ws);
+        hipLaunchKernelGGL(scatter_max_accum_kernel, grid, block, 0, st, src, lds, flat_idx, N, C, vol, count_ws);
+        hipLaunchKernelGGL(scatter_max_finalize_kernel, grid, block, 0, st, flat_idx, N, C, vol, count_ws);
     } else {
-        hipLaunchKernelGGL(scatter_accum_kernel<1>, grid, block, 0, st, src, lds, flat_idx, N, C, vol, count_ws);
-        hipLaunchKernelGGL(scatter_finalize_kernel<1>, grid, block, 0, st, flat_idx, N, C, vol, count_ws);
+        double *acc = reinterpret_cast<double *>(ws);
+        int32_t *owner_of = reinterpret_cast<int32_t *>(acc + (size_t)N * C), *npts = owner_of + N;
+        GN_HIP(hipMemsetAsync(ws, 0, gn_grid_scatter_workspace_bytes(N, C, reduce), st), "gn_grid_scatter(memset ws)");
+        hipLaunchKernelGGL(scatter_mean_owner_kernel, dim3((unsigned)gn_cdiv(N, 256)), block, 0, st, flat_idx, N, count_ws, owner_of, npts);
+        hipLaunchKernelGGL(scatter_mean_accum_kernel, grid, block, 0, st, src, lds, N, C, owner_of, acc);
+        hipLaunchKernelGGL(scatter_mean_finalize_kernel, grid, block, 0, st, flat_idx, N, C, owner_of, npts, acc, vol, count_ws);
     }
     GN_LAUNCH_CHECK("gn_grid_scatter");
     return GN_OK;

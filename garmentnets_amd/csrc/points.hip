@@ -16,7 +16,19 @@ void gn_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *gn_last_error(void) { return g_err; }
-extern "C" int gn_version(void) { return 100; }
+extern "C" int gn_version(void) { return 200; }
+hipStream_t gn_stream(void *s) {
+    hipStream_t st = (hipStream_t)s;
+    if (st) {
+        hipDevice_t dev = 0;
+        int cur = 0;
+        if (hipStreamGetDevice(st, &dev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)dev) (void)hipSetDevice((int)dev);
+    }
+    return st;
+}
+static thread_local const char *g_last_kernel = "";
+void gn_note_kernel(const char *name) { g_last_kernel = name; }
+extern "C" const char *gn_last_kernel(void) { return g_last_kernel; }
 extern "C" int gn_device_info(int *num_cu, int *lds_bytes_per_cu) {
     int dev = 0;
     hipDeviceProp_t p;

@@ -60,41 +60,75 @@ extern "C" int gn_channel_stats(const float *x, int B, int64_t V, int C, double 
     return GN_OK;
 }
 
-// one thread per (sample, group)
-__global__ void groupnorm_affine_kernel(const double *__restrict__ sum0, const double *__restrict__ sq0, int C0, int64_t V0,
+// one block per sample, one thread per group.  With `act_inv_scale` (split-operand convs): the affine of the whole sample is multiplied
+// by a power of two 2^k chosen from the statistics so that the largest per-channel rms of the normalised activations
+// y_c = a_c x + d_c (E[y^2] = a^2 E[x^2] + 2 a d E[x] + d^2, all known here) lands in [1, 2); act_inv_scale[b] = 2^-k undoes it exactly
+// in the conv epilogue.  fp16's narrow exponent then never matters: a channel's values are bounded by rms * sqrt(V) <= 2 * 2^14.5
+// < 65504 for any V < 2^29 voxels (no overflow by construction, whatever the checkpoint), and values down to 1/8 of the typical
+// magnitude keep a normal second plane (residual <= 2^-22 |x|; below that the residual is absolute, 2^-25 of the sample's scale).
+__global__ __launch_bounds__(64) void groupnorm_affine_kernel(const double *__restrict__ sum0, const double *__restrict__ sq0, int C0, int64_t V0,
                                         const double *__restrict__ sum1, const double *__restrict__ sq1, int C1, int64_t V1,
                                         int rep1, int B, int groups, float eps, const float *__restrict__ gamma,
-                                        const float *__restrict__ beta, float *__restrict__ a, float *__restrict__ d) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * groups) return;
-    const int b = t / groups, g = t % groups, C = C0 + C1, cpg = C / groups;
-    double s = 0.0, q = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        if (c < C0) { s += sum0[(int64_t)b * C0 + c]; q += sq0[(int64_t)b * C0 + c]; }
-        else { s += rep1 * sum1[(int64_t)b * C1 + c - C0]; q += rep1 * sq1[(int64_t)b * C1 + c - C0]; }
+                                        const float *__restrict__ beta, float *__restrict__ a, float *__restrict__ d,
+                                        float *__restrict__ act_inv_scale) {
+    __shared__ float gmax[64];
+    const int b = blockIdx.x, C = C0 + C1, cpg = C / groups;
+    float my_max = 0.f;
+    for (int g = threadIdx.x; g < groups; g += 64) {
+        double s = 0.0, q = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            if (c < C0) { s += sum0[(int64_t)b * C0 + c]; q += sq0[(int64_t)b * C0 + c]; }
+            else { s += rep1 * sum1[(int64_t)b * C1 + c - C0]; q += rep1 * sq1[(int64_t)b * C1 + c - C0]; }
+        }
+        const double n = (double)cpg * (double)V0;  // V0 == V1*rep1 voxels per channel after upsampling
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float fmean = (float)mean;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float ga = gamma[c] * rstd;
+            const float dd = beta[c] - fmean * ga;
+            a[(int64_t)b * C + c] = ga;
+            d[(int64_t)b * C + c] = dd;
+            if (act_inv_scale) {
+                const double ex = (c < C0 ? sum0[(int64_t)b * C0 + c] : rep1 * sum1[(int64_t)b * C1 + c - C0]) / (double)V0;
+                const double ex2 = (c < C0 ? sq0[(int64_t)b * C0 + c] : rep1 * sq1[(int64_t)b * C1 + c - C0]) / (double)V0;
+                const double ey2 = (double)ga * ga * ex2 + 2.0 * (double)ga * dd * ex + (double)dd * dd;
+                const float rms = ey2 > 0 ? (float)sqrt(ey2) : 0.f;
+                if (rms > my_max) my_max = rms;          // (a NaN statistic compares false: the scale stays finite and the NaN reaches the output)
+            }
+        }
     }
-    const double n = (double)cpg * (double)V0;  // V0 == V1*rep1 voxels per channel after upsampling
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float fmean = (float)mean;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        float ga = gamma[c] * rstd;
-        a[(int64_t)b * C + c] = ga;
-        d[(int64_t)b * C + c] = beta[c] - fmean * ga;
+    if (!act_inv_scale) return;
+    gmax[threadIdx.x] = my_max;
+    __syncthreads();
+    float m = 0.f;
+    for (int i = 0; i < 64; ++i) m = fmaxf(m, gmax[i]);
+    int e = 0;
+    float sc = 1.f, inv = 1.f;
+    if (m > 0.f && m < INFINITY) {
+        (void)frexpf(m, &e);                                 // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(1-e) in [1, 2)
+        e = 1 - e;
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+        sc = ldexpf(1.f, e);
+        inv = ldexpf(1.f, -e);
     }
+    __syncthreads();
+    for (int g = threadIdx.x; g < groups; g += 64)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a[(int64_t)b * C + c] *= sc; d[(int64_t)b * C + c] *= sc; }
+    if (threadIdx.x == 0) act_inv_scale[b] = inv;
 }
 
 extern "C" int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0, int64_t V0, const double *sum1, const double *sq1,
                                    int C1, int64_t V1, int rep1, int B, int groups, float eps, const float *gamma,
-                                   const float *beta, float *a, float *d, void *stream) {
+                                   const float *beta, float *a, float *d, float *act_inv_scale, void *stream) {
     GN_REQUIRE(B >= 0 && groups > 0 && C0 > 0 && C1 >= 0 && (C0 + C1) % groups == 0, "gn_groupnorm_affine: bad sizes");
     GN_REQUIRE(C1 == 0 || V1 * rep1 == V0, "gn_groupnorm_affine: source 1 must cover the same voxels after replication");
     if (B == 0) return GN_OK;
-    int n = B * groups;
-    hipLaunchKernelGGL(groupnorm_affine_kernel, dim3((unsigned)gn_cdiv(n, 64)), dim3(64), 0, gn_stream(stream), sum0, sq0, C0, V0, sum1,
-                       sq1, C1, V1, rep1, B, groups, eps, gamma, beta, a, d);
+    hipLaunchKernelGGL(groupnorm_affine_kernel, dim3((unsigned)B), dim3(64), 0, gn_stream(stream), sum0, sq0, C0, V0, sum1,
+                       sq1, C1, V1, rep1, B, groups, eps, gamma, beta, a, d, act_inv_scale);
     GN_LAUNCH_CHECK("gn_groupnorm_affine");
     return GN_OK;
 }
@@ -327,6 +361,7 @@ extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C
     const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
     if (wide) hipLaunchKernelGGL(conv3d_gcr_kernel<2>, dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv3d_gcr_kernel<1>, dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);
+    gn_note_kernel(wide ? "conv3d_gcr_kernel<2>" : "conv3d_gcr_kernel<1>");
     GN_LAUNCH_CHECK("gn_conv3d_gcr");
     return GN_OK;
 }

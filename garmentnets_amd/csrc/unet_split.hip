@@ -44,7 +44,8 @@ struct SplitArgs {
     double *osq;
     int C0, C1, B, D, H, W, Cout, relu;
     int tiles_y, tiles_x;
-    float out_scale;   // exact power of two undoing the pack's weight scale (1 for the bf16 modes)
+    const float *out_scale;   // [Cout] exact powers of two undoing the pack's per-output-channel weight scales (1 for the bf16 modes)
+    const float *act_inv;     // NULL or [B]: exact power of two undoing the sample's activation scale (gn_groupnorm_affine)
 };
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -351,12 +352,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
         for (int u = 0; u < NT; ++u) {
             const int t = f & 1, gz = z0 + wave + 4 * (f >> 1);
             const int n = n0 + u * 32 + r;
+            const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = __fmul_rn(tot[f][u][q], p.out_scale);
+                    float v = __fmul_rn(tot[f][u][q], osc);
                     if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
@@ -579,12 +581,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int n = n0 + u * 32 + r;
+            const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = __fmul_rn(tot[t][u][q], p.out_scale);
+                    float v = __fmul_rn(tot[t][u][q], osc);
                     if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
@@ -612,11 +615,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 }
 
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                                   const void *wp_planes, int mode, float out_scale, int B, int D, int H, int W, int Cout, int relu,
-                                   float *out, double *out_sum, double *out_sumsq, void *stream) {
+                                   const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
+                                   int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
-    GN_REQUIRE(out_scale > 0.f, "gn_conv3d_gcr_split: out_scale must be positive (1 for the bf16 modes)");
+    GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
     GN_REQUIRE(C0 % SP_KS == 0 && C1 % SP_KS == 0 && Cout % 32 == 0, "gn_conv3d_gcr_split: channel counts must be multiples of 16 (in) / 32 (out)");
     GN_REQUIRE(C1 == 0 || (src1 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: upsampled source needs even dims");
     GN_REQUIRE((out_sum == nullptr) == (out_sumsq == nullptr), "gn_conv3d_gcr_split: out_sum and out_sumsq must come together");
@@ -628,7 +631,7 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     }
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
-    p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale;
+    p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
@@ -641,12 +644,14 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     do {                                                                                                                       \
         if (wide) hipLaunchKernelGGL((conv3d_split_kernel<2, P_, F16_, 1>), dim3(tiles * (Cout / 64), B), dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_, 1>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);     \
+        gn_note_kernel(wide ? "conv3d_split_kernel<2, " #P_ ", " #F16_ ", 1>" : "conv3d_split_kernel<1, " #P_ ", " #F16_ ", 1>"); \
     } while (0)
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
     const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && (int64_t)tiles * (Cout / 128) * B >= 512;
     if (wide128) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true>" : "conv3d_split_wide_kernel<2, false>");
     } else
     if (mode == GN_SPLIT_BF16X3) SP_LAUNCH(3, false);
     else if (mode == GN_SPLIT_BF16X2) SP_LAUNCH(2, false);

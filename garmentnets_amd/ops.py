@@ -15,8 +15,16 @@ from . import _lib
 _i32 = torch.int32
 
 
+_ARG_DEVICE = [None]     # device of the tensors of the call being assembled (arguments are evaluated left to right, _stream() last)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream ON THE DEVICE OF THE CALL'S TENSORS (not of torch's current device: a model on cuda:1 with the
+    process default device 0 must launch on cuda:1's stream; the C ABI binds the HIP device to the stream's, csrc/common.h gn_stream)"""
+    dev, _ARG_DEVICE[0] = _ARG_DEVICE[0], None
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)            # the null stream means "current device" to HIP: make the two agree
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _p(t):
@@ -24,6 +32,11 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise _lib.GarmentNetsHipError("garmentnets_amd ops need tensors on the GPU (no CPU fallback)")
+    if _ARG_DEVICE[0] is None:
+        _ARG_DEVICE[0] = t.device
+    elif _ARG_DEVICE[0] != t.device:
+        dev, _ARG_DEVICE[0] = _ARG_DEVICE[0], None
+        raise _lib.GarmentNetsHipError(f"garmentnets_amd ops: tensors on different devices ({dev} vs {t.device})")
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -167,7 +180,9 @@ def grid_scatter(src, flat_idx, B, grid_shape, reduce, with_stats=False):
     vol = torch.empty((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=src.device)
     cnt = torch.empty(cells, dtype=_i32, device=src.device)
     code = {"max": 0, "mean": 1}[reduce]
-    _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _stream())
+    nbytes = _lib.load().gn_grid_scatter_workspace_bytes(N, C, code)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device) if nbytes else None
+    _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _p(ws), nbytes, _stream())
     if not with_stats:
         return vol
     s, q = _stats_buffers(B, C, src.device, True)
@@ -186,7 +201,9 @@ def channel_stats(x):
     return s, q, V
 
 
-def groupnorm_affine(st0, st1, groups, eps, gamma, beta):
+def groupnorm_affine(st0, st1, groups, eps, gamma, beta, with_act_scale=False):
+    """-> (a, d) [B][C0+C1]; with_act_scale: -> (a, d, act_inv_scale [B]) with the sample's power-of-two range normalisation folded
+    into a and d (split-operand convs: conv3d_gcr_split undoes it in the epilogue)"""
     s0, q0, V0 = st0
     B, C0 = s0.shape
     if st1 is not None:
@@ -198,9 +215,10 @@ def groupnorm_affine(st0, st1, groups, eps, gamma, beta):
         C1, V1, rep = 0, 0, 1
     a = torch.empty((B, C0 + C1), dtype=torch.float32, device=s0.device)
     d = torch.empty_like(a)
+    inv = torch.empty(B, dtype=torch.float32, device=s0.device) if with_act_scale else None
     _lib.call("gn_groupnorm_affine", _p(s0), _p(q0), C0, V0, _p(s1), _p(q1), C1, V1, rep, B, groups, float(eps), _p(gamma), _p(beta),
-              _p(a), _p(d), _stream())
-    return a, d
+              _p(a), _p(d), _p(inv), _stream())
+    return (a, d, inv) if with_act_scale else (a, d)
 
 
 def pack_conv_weight(w):
@@ -228,30 +246,35 @@ CONV_MODE = CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_M
 
 
 class SplitPack:
-    """weight planes of the split-precision conv: .tensor (int16 bit patterns, MFMA-fragment order), .mode, .out_scale"""
+    """weight planes of the split-precision conv: .tensor (int16 bit patterns, MFMA-fragment order), .mode, .out_scale (fp32 [Cout]:
+    the exact powers of two that undo the per-output-channel weight scales)"""
 
     def __init__(self, tensor, mode, out_scale):
-        self.tensor, self.mode, self.out_scale = tensor, int(mode), float(out_scale)
+        self.tensor, self.mode, self.out_scale = tensor, int(mode), out_scale
 
     def to(self, device):
-        return SplitPack(self.tensor.to(device), self.mode, self.out_scale)
+        return SplitPack(self.tensor.to(device), self.mode, self.out_scale.to(device))
 
 
 def pack_conv_weight_split(w, mode):
     """(Cout, Cin, 3,3,3) fp32 -> exact plane decomposition (w = w1 + w2 [+ w3], residual chain) in MFMA-fragment order
     [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by four zero
     (slice, tap) steps: the kernel's fragment DMA runs up to four steps ahead.  mode SPLIT_BF16X2/3: bf16 planes;
-    SPLIT_F16X2: two fp16 planes of w * 2^k, k chosen so that max|w| * 2^k is in [1, 2) (out_scale = 2^-k undoes it exactly)."""
+    SPLIT_F16X2: two fp16 planes of w * 2^k(cout), k chosen PER OUTPUT CHANNEL so that the row maximum max|w[cout]| * 2^k is in [1, 2)
+    (out_scale[cout] = 2^-k undoes it exactly): every weight within 2^3 of its row's largest keeps a normal second plane (residual
+    <= 2^-22 |w|), smaller ones are carried to 2^-25 of the row maximum -- always far below the row's own dot-product magnitude,
+    also for a heavy-tailed trained tensor (a per-TENSOR scale would push whole rows into the subnormal second plane)."""
     if mode not in (SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2):
         raise ValueError(f"unknown split mode {mode}")
     cout, cin = w.shape[:2]
     w = w.detach().float()
-    planes, dt, scale = (2, torch.float16, 1.0) if mode == SPLIT_F16X2 else (int(mode), torch.bfloat16, 1.0)
+    planes, dt = (2, torch.float16) if mode == SPLIT_F16X2 else (int(mode), torch.bfloat16)
+    scale = torch.ones(cout, dtype=torch.float32)
     if mode == SPLIT_F16X2:
-        m = float(w.abs().max())
-        if m > 0 and math.isfinite(m):
-            scale = 2.0 ** (-math.floor(math.log2(m)))
-    base = (w * scale).permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 2, 8, cout // 32, 32)                # [tap][S][h][8][blk][r]
+        m = w.reshape(cout, -1).abs().amax(dim=1).cpu()
+        ok = torch.isfinite(m) & (m > 0)
+        scale = torch.where(ok, torch.exp2(-torch.floor(torch.log2(torch.where(ok, m, torch.ones_like(m))))), scale).float()
+    base = (w * scale.to(w.device).view(cout, 1, 1, 1, 1)).permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 2, 8, cout // 32, 32)                # [tap][S][h][8][blk][r]
     base = base.permute(1, 0, 4, 2, 5, 3)                                                                # [S][tap][blk][h][r][8]
     out, r = [], base
     for _ in range(planes):
@@ -261,15 +284,15 @@ def pack_conv_weight_split(w, mode):
     pk = torch.stack(out, dim=3).contiguous()                                                            # [S][tap][blk][planes][h][r][8]
     pk = pk.reshape(cin // 16 * 27, -1)
     pk = torch.cat([pk, torch.zeros_like(pk[:4])], dim=0)
-    return SplitPack(pk.contiguous().view(torch.int16), mode, 1.0 / scale)
+    return SplitPack(pk.contiguous().view(torch.int16), mode, (1.0 / scale).contiguous().to(w.device))
 
 
-def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False):
+def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
-    _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, pack.out_scale, B, D, H, W, cout,
+    _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
               1 if relu else 0, _p(out), _p(s), _p(q), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 

@@ -134,6 +134,7 @@ def main(argv=None):
     ap.add_argument("--num_views", type=int, default=4)
     a = ap.parse_args(argv)
     device = torch.device("cuda:{}".format(a.gpu_id))
+    torch.cuda.set_device(device)       # main.gpu_id of the reference config: every allocation, stream and kernel of this process goes there
     if a.checkpoint_path:
         model = ConvImplicitWNFPipeline.load_from_checkpoint(a.checkpoint_path)
     else:

@@ -122,11 +122,13 @@ def synthetic_state_dict(hp, seed=0):
     return {k: synthetic_tensor(k, shp, seed) for k, shp in state_dict_spec(hp)}
 
 
-def synthetic_cloud(num_garments, n_points=6000, seed=0):
-    """-> x (N,3) rgb in [0,1], pos (N,3) metres in the gripper frame, batch (N,) int64 sorted."""
+def synthetic_cloud(num_garments, n_points=6000, seed=0, first=0):
+    """-> x (N,3) rgb in [0,1], pos (N,3) metres in the gripper frame, batch (N,) int64 sorted.
+    Garment g of the seed's stream depends on (seed, g) only: ``first`` selects garments first..first+num_garments-1, i.e. exactly the
+    slice [first, first+num) of the global batch synthetic_cloud(total, n, seed) (a rank's shard of it, batch ids restarting at 0)."""
     xs, ps, bs = [], [], []
     for b in range(num_garments):
-        rng = np.random.Generator(np.random.PCG64(seed * 1000003 + b))
+        rng = np.random.Generator(np.random.PCG64(seed * 1000003 + first + b))
         while True:
             th = rng.uniform(0, 2 * np.pi, n_points)
             h = rng.uniform(0, 0.8, n_points)

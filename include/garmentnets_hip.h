@@ -33,6 +33,9 @@ extern "C" {
 
 const char *gn_last_error(void);
 int gn_version(void);
+/* name of the kernel variant the last gn_conv3d_gcr / gn_conv3d_gcr_split call of this thread launched (static string; ""
+ * before the first call): measurement code labels its per-kernel timings with what really ran, not with a re-derived dispatch rule */
+const char *gn_last_kernel(void);
 /* number of CUs / XCDs the library sees on the current device (sanity: 256 / 8 on MI355X) */
 int gn_device_info(int *num_cu, int *lds_bytes_per_cu);
 
@@ -107,9 +110,12 @@ int gn_grid_features(const float *feat, int ldf, int Cf, const float *nocs, cons
 
 /* Scatter point features into a zero-filled channel-last volume.  replaces torch_scatter.scatter(reduce) --
  * networks/conv_implicit_wnf.py:92-94.  reduce: 0 = max, 1 = mean.  vol [cells][C] must be zeroed by this
- * call (it does the memset); count_ws: [cells] int32 workspace.  Empty cells stay 0. */
+ * call (it does the memset); count_ws: [cells] int32 workspace.  Empty cells stay 0.  Both reductions are
+ * deterministic (run-to-run bit-identical): max by construction, mean through order-independent fp64 partial sums
+ * kept in `ws` (gn_grid_scatter_workspace_bytes(N, C, reduce) bytes; 0 / NULL for max). */
+size_t gn_grid_scatter_workspace_bytes(int64_t N, int C, int reduce);
 int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
-                    float *vol, int32_t *count_ws, void *stream);
+                    float *vol, int32_t *count_ws, void *ws, size_t ws_bytes, void *stream);
 
 /* Per-(sample, channel) sum / sum of squares of a scattered volume computed from its OCCUPIED cells only (all other
  * cells are zero): the GroupNorm statistics of the first UNet layer without reading the (mostly empty) volume.
@@ -127,10 +133,13 @@ int gn_channel_stats(const float *x, int B, int64_t V, int C, double *sum, doubl
 
 /* GroupNorm statistics -> per-(sample, channel) affine  y = x*a + d  for the concatenation of up to two
  * sources (src0: C0 channels, V0 voxels; src1: C1 channels, V1 voxels each replicated rep1 times = nearest
- * upsampling).  groups over C0+C1 channels, eps, biased variance (nn.GroupNorm).  a,d: [B][C0+C1]. */
+ * upsampling).  groups over C0+C1 channels, eps, biased variance (nn.GroupNorm).  a,d: [B][C0+C1].
+ * act_inv_scale (NULL, or [B]): range normalisation for the split-operand convs -- a and d of sample b are multiplied by the power
+ * of two that brings the largest per-channel rms of the normalised activations into [1, 2) and act_inv_scale[b] receives its
+ * inverse (gn_conv3d_gcr_split undoes it exactly in its epilogue).  fp16 planes then cannot overflow for any checkpoint. */
 int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0, int64_t V0, const double *sum1, const double *sq1,
                         int C1, int64_t V1, int rep1, int B, int groups, float eps, const float *gamma,
-                        const float *beta, float *a, float *d, void *stream);
+                        const float *beta, float *a, float *d, float *act_inv_scale, void *stream);
 
 /* Fused GroupNorm-apply + Conv3d(3x3x3, pad 1, no bias) + ReLU, the 'gcr' SingleConv --
  * components/unet3d.py:53-66,19-76.  Input = channel concatenation [src0 (C0 ch, full res), src1 (C1 ch, HALF
@@ -149,17 +158,19 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
  * fp32 operands are decomposed into low-precision planes (x = x1 + x2 [+ x3], exact residual chain) and multiplied on the
  * 16-bit matrix cores with fp32 accumulation:
  *   GN_SPLIT_BF16X3: 3 bf16 planes, 6 partial products, dropped terms <= 2^-24 relative (fp32-class products)
- *   GN_SPLIT_F16X2 : 2 fp16 planes, 3 partial products, operand residual and dropped term <= 2^-22 relative
+ *   GN_SPLIT_F16X2 : 2 fp16 planes, 3 partial products, operand residual and dropped term <= 2^-22 relative for operands within
+ *                    2^3 of their scale (below: absolute, 2^-25 of the scale).  Scales: one power of two per OUTPUT CHANNEL for the
+ *                    weights (row maximum in [1, 2)) and one per SAMPLE for the activations (gn_groupnorm_affine act_inv_scale)
  *   GN_SPLIT_BF16X2: 2 bf16 planes, 3 partial products, 2^-16 relative (fast preview quality)
  * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + four zero steps
- * (garmentnets_amd.ops.pack_conv_weight_split); out_scale: the exact power of two that undoes the pack's weight scale
- * (fp16 mode; 1 for bf16). */
+ * (garmentnets_amd.ops.pack_conv_weight_split); out_scale [Cout]: the exact powers of two that undo the pack's per-output-channel
+ * weight scales (all 1 for bf16); act_inv_scale: NULL or [B] from gn_groupnorm_affine. */
 #define GN_SPLIT_BF16X2 2
 #define GN_SPLIT_BF16X3 3
 #define GN_SPLIT_F16X2 4
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                        const void *wp_planes, int mode, float out_scale, int B, int D, int H, int W, int Cout, int relu, float *out,
-                        double *out_sum, double *out_sumsq, void *stream);
+                        const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H, int W,
+                        int Cout, int relu, float *out, double *out_sum, double *out_sumsq, void *stream);
 
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */

@@ -1,0 +1,267 @@
+"""GPU (-m gpu): the HEADLINE configuration at its real sizes (BASELINE.json configs 2, 3, 5).
+
+bench.py quotes garments/s at batch 16, 6000-point clouds, a 128^3 feature volume (mean) and a 128^3 / 256^3 WNF lattice.  The
+fixture-sized parity tests (tests/test_gpu_parity.py) stop at G=32; this file runs the same HIP path at the sizes the number is
+quoted on and checks it
+  * against the CPU oracle (oracle/pipeline.py, ~20-30 s of host time per 128^3 UNet pass -- done once per module), and
+  * through size-independent properties: a garment's result must not depend on its slot in a 16- or 32-garment batch
+    (16 x 128^3 x 128 channels = 4.3 G elements: every >2^31 element offset in conv / pool / stats / sampler / decoder is crossed).
+fp32 tolerances are written next to each check (north_star: 1e-4 on WNF / NOCS); index results are bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pipeline as P  # noqa: E402
+from garmentnets_amd import ops, synthetic as S  # noqa: E402
+from garmentnets_amd.batch import Batch  # noqa: E402
+from garmentnets_amd.components.unet3d import to_channel_last  # noqa: E402
+from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-4
+G, Q, NPTS = 128, 128, 6000
+
+
+def _oracle_threads():
+    # torch-CPU conv3d collapses under oversubscription (256 threads are 27x slower than 32 on the MI355X host)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+
+
+def _model(hp, seed, self_loops=True):
+    m = ConvImplicitWNFPipeline(**hp)
+    m.load_state_dict(S.synthetic_state_dict(hp, seed))
+    m = m.to(DEV).eval().requires_grad_(False)
+    m.pointnet2_nocs.sa1_module.conv.add_self_loops = self_loops
+    m.pointnet2_nocs.sa2_module.conv.add_self_loops = self_loops
+    return m
+
+
+def _batch(B, seed, n=NPTS):
+    x, pos, batch = S.synthetic_cloud(B, n, seed=seed)
+    return Batch(sizes=[n] * B, x=x, pos=pos, batch=batch)
+
+
+@pytest.fixture(scope="module")
+def full128():
+    """one garment through the whole dense path at G=128 (mean) / Q=128: HIP results + the oracle's, computed once"""
+    _oracle_threads()
+    hp = S.default_hparams(grid=G, reduce_method="mean")
+    sd = S.synthetic_state_dict(hp, 0)
+    data = _batch(1, 3)
+    model = _model(hp, 0)
+    with torch.no_grad():
+        p2 = model.pointnet2_forward(data.to(DEV))
+        vin = model.volume_agg(p2["nocs_data"])
+        u3 = model.unet3d_forward(p2)
+        wnf = model.volume_lattice_forward(u3, Q)["pred_volume"][0]
+        ref_p2 = P.pointnet2_forward(sd, hp, data.x, data.pos, data.batch)
+        ref_vin = P.volume_agg(sd, hp["volume_agg_params"], ref_p2["nocs_data"], 1)
+        ref_vol = P.unet3d(sd, hp["unet3d_params"], ref_vin)
+        ref_wnf = P.decode_volume(sd, ref_vol, Q)
+    return dict(hp=hp, sd=sd, data=data, model=model, p2=p2, vin=vin, u3=u3, wnf=wnf, ref_p2=ref_p2, ref_vin=ref_vin, ref_vol=ref_vol,
+                ref_wnf=ref_wnf)
+
+
+def test_full_size_single_garment_against_oracle(full128):
+    """config[2] sizes, B=1, end to end against the fp32 oracle chain: NOCS bins exact, cell occupancy exact, scattered volume within
+    1e-4.  With the seeded synthetic weights the 6000 points collapse into a handful of cells (> 1000 points each); GroupNorm over a
+    > 99.99 % empty 128^3 volume then amplifies the 1e-5 difference between two valid fp32 means of a cell by ~100x, and the REFERENCE
+    arithmetic itself sits 1.1e-4 from the exact (fp64) WNF (next test).  So the end-to-end feature volume / WNF are only bounded
+    loosely here (5e-4, relative for the volume); the 1e-4 bar is enforced where the problem is well conditioned
+    (test_full_size_realistic_occupancy_against_oracle) and against the exact result (test_full_size_unet_and_decoder_against_fp64)."""
+    f = full128
+    bins, _, _ = ops.nocs_head(f["p2"]["per_point_logits"], 64)
+    assert torch.equal(bins.cpu(), f["ref_p2"]["nocs_data"]["nocs_bin_idx"])
+    vin = f["vin"].cpu()
+    assert torch.equal(vin != 0, f["ref_vin"] != 0)                                   # the same cells are occupied
+    err_in = float((vin - f["ref_vin"]).abs().max())
+    vol = f["u3"]["out_feature_volume"]
+    assert vol.shape == (1, 128, G, G, G)
+    err_vol, mag = float((vol.cpu() - f["ref_vol"]).abs().max()), float(f["ref_vol"].abs().max())
+    err_wnf = float((f["wnf"].cpu() - f["ref_wnf"]).abs().max())
+    occ = int((f["ref_vin"][0] != 0).any(dim=0).sum())
+    print(f"G=128 B=1 end to end vs fp32 oracle ({occ} occupied cells): in-volume err {err_in:.2e}, out-volume err {err_vol:.2e} (max |v| {mag:.1f}), "
+          f"WNF err {err_wnf:.2e}")
+    assert err_in <= TOL and err_wnf <= 5e-4 and err_vol <= 5e-4 * max(1.0, mag)
+
+
+def test_full_size_unet_and_decoder_against_fp64(full128):
+    """the dense stages at G=128 / Q=128 on IDENTICAL input (the oracle's scattered volume, uploaded): HIP path vs the fp64 restatement,
+    next to the fp32 oracle vs the same fp64 truth.  The HIP path must be at least as close to the exact result as the reference's own
+    fp32 arithmetic is (factor 2 + a 2.5e-5 floor), on the whole 128-channel volume and the whole WNF lattice."""
+    _oracle_threads()
+    f = full128
+    model, hp = f["model"], f["hp"]
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in f["sd"].items()}
+    with torch.no_grad():
+        vol64 = P.unet3d(sd64, hp["unet3d_params"], f["ref_vin"].double())
+        gp = P.grid_points(Q).reshape(1, -1, 3)
+        wnf64 = torch.cat([P.implicit_decoder(sd64, "volume_decoder", vol64, gp[:, i:i + (1 << 18)].double()) for i in range(0, Q ** 3, 1 << 18)], dim=1).view(Q, Q, Q)
+        net = model.unet_3d.abstract_3d_unet
+        from garmentnets_amd.networks.conv_implicit_wnf import UNetResult
+        u3 = UNetResult(net.run(to_channel_last(f["ref_vin"].to(DEV)), None, pre_final=True), net.final_conv)   # dense statistics path
+        wnf = model.volume_lattice_forward(u3, Q)["pred_volume"][0].cpu()
+        vol = u3["out_feature_volume"].cpu()
+    e_gpu_vol, e_ref_vol = float((vol - vol64).abs().max()), float((f["ref_vol"] - vol64).abs().max())
+    e_gpu_wnf, e_ref_wnf = float((wnf - wnf64).abs().max()), float((f["ref_wnf"] - wnf64).abs().max())
+    print(f"G=128 vs fp64: feature volume HIP {e_gpu_vol:.2e} / fp32 oracle {e_ref_vol:.2e}; WNF HIP {e_gpu_wnf:.2e} / fp32 oracle {e_ref_wnf:.2e}")
+    assert e_gpu_vol <= 2 * max(e_ref_vol, 2.5e-5) and e_gpu_wnf <= 2 * max(e_ref_wnf, 2.5e-5)
+
+
+def test_full_size_realistic_occupancy_against_oracle(full128):
+    """G=128 / Q=128 with the occupancy a trained PointNet++ produces: the NOCS coordinates are the garment's own (normalised, 64-bin
+    quantised) point positions instead of the collapsed predictions of random weights -> thousands of occupied cells, a well-conditioned
+    GroupNorm.  Both chains consume the same per-point features; scatter (mean), sparse GroupNorm statistics, UNet, 128^3 lattice decode:
+    cells exact, feature volume and WNF within 1e-4 of the fp32 oracle."""
+    _oracle_threads()
+    f = full128
+    model, hp, sd, data = f["model"], f["hp"], f["sd"], f["data"]
+    pos = data.pos
+    nrm = 0.1 + 0.8 * (pos - pos.min(dim=0)[0]) / (pos.max(dim=0)[0] - pos.min(dim=0)[0])
+    nocs = torch.round(nrm * 63).to(torch.float32) * (1.0 / 63)
+    feat, conf = f["p2"]["per_point_features"].cpu().contiguous(), f["p2"]["nocs_data"].pred_confidence.cpu().contiguous()
+    with torch.no_grad():
+        ref_vin = P.volume_agg(sd, hp["volume_agg_params"], dict(x=feat, pos=nocs, batch=data.batch, sim_points=pos, pred_confidence=conf), 1)
+        ref_vol = P.unet3d(sd, hp["unet3d_params"], ref_vin)
+        ref_wnf = P.decode_volume(sd, ref_vol, Q)
+        nd = Batch(sizes=[NPTS], x=feat, pos=nocs, batch=data.batch, sim_points=pos, pred_confidence=conf).to(DEV)
+        vin = model.volume_agg(nd)
+        u3 = model.unet3d_forward({"nocs_data": nd})
+        wnf = model.volume_lattice_forward(u3, Q)["pred_volume"][0].cpu()
+    occ = int((ref_vin[0] != 0).any(dim=0).sum())
+    assert occ > 2000
+    assert torch.equal(vin.cpu() != 0, ref_vin != 0)
+    e_in = float((vin.cpu() - ref_vin).abs().max())
+    e_vol, mag = float((u3["out_feature_volume"].cpu() - ref_vol).abs().max()), float(ref_vol.abs().max())
+    e_wnf = float((wnf - ref_wnf).abs().max())
+    print(f"G=128 realistic occupancy ({occ} cells): in-volume err {e_in:.2e}, out-volume err {e_vol:.2e} (max |v| {mag:.1f}), WNF err {e_wnf:.2e}")
+    assert e_in <= 1e-6 and e_wnf <= TOL and e_vol <= TOL * max(1.0, mag)
+
+
+def test_full_size_dense_unet_against_oracle():
+    """the UNet alone on a DENSE N(0,1) 128^3 volume (every voxel differs -- the scattered volume above is >99 % empty) vs the oracle"""
+    _oracle_threads()
+    hp = S.default_hparams(grid=G)
+    sd = S.synthetic_state_dict(hp, 5)
+    model = _model(hp, 5)
+    x = torch.randn(1, 128, G, G, G, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y = model.unet_3d(x.to(DEV)).cpu()
+        ref = P.unet3d(sd, hp["unet3d_params"], x)
+    err = (y - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"dense UNet G=128: max |y| {scale:.2f}, max err {float(err.max()):.2e}")
+    assert bool((err <= TOL + 1e-4 * ref.abs()).all())
+
+
+def test_q256_lattice_against_oracle(full128):
+    """config[5]: the 256^3 WNF lattice of one garment; every 8th lattice point per axis (32 768 queries) against the oracle's decoder
+    run on the HIP path's own 128-channel volume, and against the per-query API path (bit-identical)"""
+    f = full128
+    model, u3 = f["model"], f["u3"]
+    with torch.no_grad():
+        wnf = model.volume_lattice_forward(u3, 256)["pred_volume"][0]
+        sub = wnf[::8, ::8, ::8].contiguous()
+        q = P.grid_points(256)[::8, ::8, ::8].reshape(1, -1, 3).contiguous()
+        api = model.volume_decoder_forward(u3, q.to(DEV))["pred_volume_value"].view(32, 32, 32)
+        ref = P.implicit_decoder(f["sd"], "volume_decoder", u3["out_feature_volume"].cpu().contiguous(), q).view(32, 32, 32)
+    assert torch.equal(api, sub)
+    err = float((sub.cpu() - ref).abs().max())
+    print(f"Q=256 strided lattice vs oracle: {err:.2e}")
+    assert err <= TOL
+    assert bool(torch.isfinite(wnf).all())
+
+
+def test_batch16_replicated_volume_is_slot_independent(full128):
+    """B=16 x 128^3: one input volume replicated 16x through the UNet + the 128^3 lattice decode.  Every slot must reproduce the B=1
+    result (GroupNorm statistics are accumulated with fp64 atomics whose order is free, so equality is up to the last fp32 bit of
+    the per-channel affine: 1e-5 absolute; an offset overflow gives garbage, not 1e-6)"""
+    f = full128
+    model = f["model"]
+    net = model.unet_3d.abstract_3d_unet
+    vin = to_channel_last(f["vin"])                       # [1][G][G][G][128]
+    B = 16
+    with torch.no_grad():
+        pre1 = net.run(vin, None, pre_final=True)
+        rep = vin.expand(B, -1, -1, -1, -1).contiguous()
+        assert rep.numel() > 2 ** 31
+        pre = net.run(rep, None, pre_final=True)
+        del rep
+        worst = 0.0
+        for b in range(B):
+            worst = max(worst, float((pre[b] - pre1[0]).abs().max()))
+        from garmentnets_amd.networks.conv_implicit_wnf import UNetResult
+        wnf1 = model.volume_lattice_forward(UNetResult(pre1, net.final_conv), Q)["pred_volume"][0]
+        wnf = model.volume_lattice_forward(UNetResult(pre, net.final_conv), Q)["pred_volume"]
+        worst_wnf = max(float((wnf[b] - wnf1).abs().max()) for b in range(B))
+    print(f"B=16 replicated: pre-final volume slot spread {worst:.2e}, WNF spread {worst_wnf:.2e}")
+    assert worst <= 1e-5 * max(1.0, float(pre1.abs().max())) and worst_wnf <= 1e-5
+
+
+@pytest.mark.parametrize("B,slots", [(16, (0, 7, 15)), (32, (31,))])
+def test_full_size_batch_slot_independence(B, slots):
+    """config[2] / config[1] batch sizes with DIFFERENT garments per slot: with PointConv's bipartite self-loop quirk switched off
+    (it links centre i to point i of the whole batch) a garment's result cannot depend on its slot.  fps order and
+    ball-query tables bit-equal (up to the slot's point offset), features bit-equal, scattered volume / WNF within 1e-5 (the mean scatter is order-independent; the GroupNorm statistics are fp64 atomics)."""
+    hp = S.default_hparams(grid=G, reduce_method="mean")
+    model = _model(hp, 0, self_loops=False)
+    data = _batch(B, 11)
+    pn = model.pointnet2_nocs
+    with torch.no_grad():
+        p2 = model.pointnet2_forward(data.to(DEV))
+        g1, g2 = pn.sa1_module.last_graph, pn.sa2_module.last_graph
+        full = B <= 16
+        if full:
+            u3 = model.unet3d_forward(p2)
+            wnf = model.volume_lattice_forward(u3, Q)["pred_volume"]
+        for b in slots:
+            sl = slice(b * NPTS, (b + 1) * NPTS)
+            one = Batch(sizes=[NPTS], x=data.x[sl], pos=data.pos[sl], batch=torch.zeros(NPTS, dtype=torch.int64)).to(DEV)
+            q2 = model.pointnet2_forward(one)
+            h1, h2 = pn.sa1_module.last_graph, pn.sa2_module.last_graph
+            m1, m2 = NPTS // 2, NPTS // 8
+            assert torch.equal(g1[0][b * m1:(b + 1) * m1] - b * NPTS, h1[0])                     # fps order, SA1
+            assert torch.equal(g2[0][b * m2:(b + 1) * m2] - b * m1, h2[0])                       # fps order, SA2
+            for (gi, off, m), hi in (((g1, b * NPTS, m1), h1), ((g2, b * m1, m2), h2)):
+                nb = gi[1][b * m:(b + 1) * m]
+                assert torch.equal(torch.where(nb >= 0, nb - off, nb), hi[1])                    # ball-query tables
+            assert torch.equal(p2["per_point_logits"][sl], q2["per_point_logits"])
+            assert torch.equal(p2["per_point_features"][sl], q2["per_point_features"])
+            assert torch.equal(p2["global_feature"][b], q2["global_feature"][0])
+            assert torch.equal(p2["nocs_data"].pos[sl], q2["nocs_data"].pos)
+            if full:
+                v3 = model.unet3d_forward(q2)
+                w1 = model.volume_lattice_forward(v3, Q)["pred_volume"][0]
+                e_pre = float((u3.pre_final[b] - v3.pre_final[0]).abs().max())
+                e_wnf = float((wnf[b] - w1).abs().max())
+                print(f"B={B} slot {b}: pre-final spread {e_pre:.2e}, WNF spread {e_wnf:.2e}")
+                assert e_pre <= 1e-5 and e_wnf <= 1e-5
+
+
+def test_predict_batch16_meshes_match_single_garment_runs():
+    """the whole predict path (incl. GGM, marching cubes, surface decode, batched graph-replayed tail) at B=16/G=128/Q=128, self-loop
+    quirk off: garments 0 and 15 of the batch against the same garment predicted alone -- mesh topology equal whenever the two WNF
+    volumes agree on the side of the level for every voxel (they differ by float-atomic order only), values within 1e-5"""
+    from garmentnets_amd.predict import predict_batch
+    hp = S.default_hparams(grid=G, reduce_method="mean")
+    model = _model(hp, 0, self_loops=False)
+    B = 16
+    data = _batch(B, 21)
+    res = predict_batch(model, data.to(DEV), volume_size=Q, auto_level=True)
+    assert len(res) == B
+    for b in (0, B - 1):
+        sl = slice(b * NPTS, (b + 1) * NPTS)
+        one = Batch(sizes=[NPTS], x=data.x[sl], pos=data.pos[sl], batch=torch.zeros(NPTS, dtype=torch.int64)).to(DEV)
+        r1 = predict_batch(model, one, volume_size=Q, auto_level=True)[0]
+        assert float((res[b]["wnf_volume"] - r1["wnf_volume"]).abs().max()) <= 1e-5
+        assert res[b]["verts"].shape[0] > 100 and not bool(torch.isnan(res[b]["verts"]).any())
+        if torch.equal(res[b]["faces"].cpu(), r1["faces"].cpu()):
+            assert float((res[b]["verts"] - r1["verts"]).abs().max()) <= 1e-3
+            assert float((res[b]["warp_field"] - r1["warp_field"]).abs().max()) <= 1e-3
+        else:   # a voxel within float-atomic noise of the level flipped: sizes still have to agree closely
+            assert abs(res[b]["faces"].shape[0] - r1["faces"].shape[0]) <= 0.01 * r1["faces"].shape[0] + 8

@@ -14,7 +14,7 @@ def run(lib, tag, B, G, C0, Cout, mode, reps=3):
     out = torch.empty(B, G, G, G, Cout, device=dev)
     fl = 54.0 * C0 * Cout * B * G ** 3
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    f = lambda: lib.gn_conv3d_gcr_split(P_(x), C0, None, 0, P_(a), P_(d), P_(pk.tensor), mode, ctypes.c_float(pk.out_scale), B, G, G, G, Cout, 1, P_(out), None, None, st)
+    f = lambda: lib.gn_conv3d_gcr_split(P_(x), C0, None, 0, P_(a), P_(d), P_(pk.tensor), mode, P_(pk.out_scale), None, B, G, G, G, Cout, 1, P_(out), None, None, st)
     assert f() == 0; torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); [f() for _ in range(reps)]; e1.record(); torch.cuda.synchronize()
