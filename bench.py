@@ -131,7 +131,7 @@ class KernelTimer:
         ops.knn_interpolate = self._wrap(ops.knn_interpolate, d_knn)
         ops.linear = self._wrap(ops.linear, d_lin)
         if hasattr(ops, "sa_fused"):
-            def d_sa(out, x, pos, centre_idx, nbr, pack, **kw):
+            def d_sa(out, x, pos, centre_idx, nbr, cnt, pack, **kw):
                 M, K = nbr.shape
                 return "sa_fused_kernel", 2.0 * M * (K + 1) * pack.macs_per_edge, (M * (K + 1) * (pack.cin + 3) + M * pack.cout) * 4.0
             ops.sa_fused = self._wrap(ops.sa_fused, d_sa)
@@ -309,9 +309,8 @@ def main():
     model = model.to(dev).eval().requires_grad_(False)
     # the global batch of batch x world garments (one seed), sharded contiguously: this rank owns garments [lo, hi)
     global_batch = args.batch * world
-    lo, hi = parallel.shard_range(global_batch, rank, world)
-    x, pos, batch = S.synthetic_cloud(hi - lo, args.points, seed=CLOUD_SEED, first=lo)
-    host_data = Batch(sizes=[args.points] * (hi - lo), x=x.pin_memory(), pos=pos.pin_memory(), batch=batch.pin_memory())
+    shard, (lo, hi) = parallel.shard_batch(global_batch, args.points, CLOUD_SEED, rank, world)
+    host_data = Batch(sizes=shard.sizes, x=shard.x.pin_memory(), pos=shard.pos.pin_memory(), batch=shard.batch.pin_memory())
     data = host_data.to(dev)                         # resident in HBM before timing
     timer = KernelTimer()
     if args.workload == "pointnet2":

@@ -23,6 +23,8 @@ PROTOTYPES = {
     "gn_ball_query": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp],
     "gn_sa_gather": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp],
     "gn_segment_max": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_sa_fused_supported": [_i32, _i32, _i32, _i32],
+    "gn_sa_fused": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_global_max_pool": [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
     "gn_knn_interpolate": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_linear": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
@@ -38,17 +40,20 @@ PROTOTYPES = {
     "gn_grid_stats": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_trilinear_sample": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i32, _vp],
     "gn_implicit_decode": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
-                           _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
+                           _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "gn_ggm3d": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
     "gn_minmax": [_vp, _i64, _vp, _vp],
     "gn_mc33_workspace_bytes": [_i32, _i32, _i32],
     "gn_mc33": [_vp, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "gn_gather_nn": [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _vp, _vp],
+    "gn_mesh_compact_workspace_bytes": [_i64, _i64],
+    "gn_mesh_compact": [_vp, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp],
     "gn_scale_verts": [_vp, _i64, _f64, _vp, _vp],
-    "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _f32, _f32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
-_RESTYPES = {"gn_mc33_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz}
+_RESTYPES = {"gn_mc33_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz}
 
 _lib = None
 

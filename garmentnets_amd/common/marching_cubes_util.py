@@ -157,7 +157,11 @@ def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_
 
 
 def delete_invalid_verts(mc_verts, mc_faces, is_vert_on_surface):
-    """common/marching_cubes_util.py:38-52 on torch tensors (any device)."""
+    """common/marching_cubes_util.py:38-52.  Device tensors: the scan-based compaction kernel (csrc/iso.hip gn_mesh_compact; faces come
+    back in the dtype they came in).  Host tensors (eval-side use on arrays read back from prediction.zarr): the same thing in torch."""
+    if mc_verts.is_cuda:
+        v, f = ops.mesh_compact(mc_verts, mc_faces, is_vert_on_surface)
+        return v, f.to(mc_faces.dtype)
     keep_face = is_vert_on_surface[mc_faces.long()].all(dim=1)
     faces = mc_faces[keep_face].long()
     used = torch.unique(faces.flatten())

@@ -14,6 +14,10 @@ import torch
 from .. import ops
 
 
+import os
+
+FUSED_SA = os.environ.get("GARMENTNETS_FUSED_SA", "1") != "0"      # False: the unfused gather -> gn_linear x3 -> segment-max chain
+
 _PTR_CACHE = {}      # (sizes, device) -> device int32 CSR ptr.  Batch shapes repeat from step to step: no per-step host-to-device copy,
                      # and nothing that a HIP-graph capture of the forward pass could not record (garmentnets_amd/graphs.py)
 
@@ -93,12 +97,39 @@ class SAModule(torch.nn.Module):
         if self.random_start:
             start = torch.tensor([int(torch.randint(0, max(n, 1), (1,))) for n in seg.sizes], dtype=torch.int32).to(pos.device)
         idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total, start)
-        nbr, _ = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
-        edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops)
-        h = self.conv.local_nn(edges)
-        out = ops.segment_max(h, slot_src, cseg.total, S)
+        nbr, cnt = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
+        pack = self._fused_pack() if FUSED_SA else None
+        if pack is not None and x is not None and x.shape[1] == pack.cin:
+            # one kernel: gather -> edge MLP on the matrix cores -> BatchNorm -> max; no edge tensor in HBM (csrc/sa_fused.hip)
+            out = ops.sa_fused(x, pos, idx, nbr, cnt, pack, self_loops=self.conv.add_self_loops)
+        else:
+            edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops)
+            h = self.conv.local_nn(edges)
+            out = ops.segment_max(h, slot_src, cseg.total, S)
         self.last_graph = (idx, nbr)
         return out, pos[idx.long()], cseg
+
+    def _fused_pack(self):
+        """SaFusedPack of local_nn when it is one of the edge MLPs gn_sa_fused is instantiated for, else None (cached per parameter version)"""
+        nn_ = self.conv.local_nn
+        blocks = list(nn_) if nn_ is not None else []
+        if len(blocks) != 3:
+            return None
+        dims = [b[0].out_features for b in blocks]
+        cin = blocks[0][0].in_features - 3
+        if not ops.sa_fused_supported(cin, dims):
+            return None
+        key = tuple((p._version, p.device) for p in nn_.parameters()) + tuple(b._version for b in nn_.buffers())
+        cached = self.__dict__.get("_sa_pack")
+        if cached is None or cached[0] != key:
+            from .mlp import fold_batchnorm
+            layers = []
+            for b in blocks:
+                sc, sh = fold_batchnorm(b[2]) if len(b) > 2 else (None, None)
+                layers.append((b[0].weight, b[0].bias, sc, sh))
+            cached = (key, ops.pack_sa_fused(layers).to(blocks[0][0].weight.device))
+            self.__dict__["_sa_pack"] = cached
+        return cached[1]
 
 
 class GlobalSAModule(torch.nn.Module):

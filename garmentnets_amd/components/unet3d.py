@@ -136,7 +136,7 @@ class Abstract3DUNet(nn.Module):
         self.final_conv = FinalConv1x1(f_maps[0], out_channels, 1)
         self.final_activation = None
 
-    def run(self, x, stats=None, pre_final=False):
+    def run(self, x, stats=None, pre_final=False, return_stats=False):
         """channel-last in, channel-last out (pre_final: stop before the final 1x1x1 convolution -- it is linear, so the decoders can
         fold it into their first layer and sample the f_maps[0]-channel volume instead: networks/conv_implicit_wnf.py UNetResult).  Every kernel that produces a tensor also emits the per-channel statistics the
         next GroupNorm needs (conv / max-pool epilogues), so no activation is re-read for normalisation."""
@@ -146,7 +146,9 @@ class Abstract3DUNet(nn.Module):
             feats.insert(0, (x, stats))
         for dec, (skip, skip_stats) in zip(self.decoders, feats[1:]):
             x, stats = dec.run(skip, x, skip_stats, stats)
-        return x if pre_final else self.final_conv.run(x)
+        if pre_final:       # return_stats: + (sum, sumsq, V) of the pre-final volume (the decoders derive their input scale from it)
+            return (x, stats) if return_stats else x
+        return self.final_conv.run(x)
 
     def forward(self, x):
         """x: (B, C, D, H, W) as in the reference; returns (B, C', D, H, W) (a view over channel-last storage)."""

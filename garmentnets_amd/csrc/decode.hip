@@ -258,6 +258,7 @@ struct DecodeArgs {
     const float *w2p, *b2, *s2, *t2; int N2;
     const float *w3, *b3, *s3, *t3; int OUT;
     float *out; int ldo;
+    const float *run_if;                  // NULL, or a device flag: the kernel does nothing unless *run_if != 0
 };
 
 #define DEC_TM 32
@@ -379,6 +380,7 @@ template <int OUTC>
 __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.run_if && *p.run_if == 0.f) return;       // gated launch (the split-operand kernel handled these rows)
     const int ldp = p.C0 + 4, ldq = p.N1 + 4;
     float *P = dsm, *Qb = dsm + DEC_TM * ldp, *red = Qb + DEC_TM * ldq;   // X0 | H1 | 8 x 32 x OUT partial dot products
     const long long mb = (long long)blockIdx.x * DEC_TM;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
 extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
                                   const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
                                   const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
-                                  const float *s3, const float *t3, int OUT, float *out, int ldo, void *stream) {
+                                  const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, void *stream) {
     GN_REQUIRE((xin != nullptr || (vol != nullptr && D > 0 && H > 0 && W > 0)) && M >= 0 && ldo >= OUT, "gn_implicit_decode: bad sizes");
     if (M == 0) return GN_OK;
     GN_REQUIRE(xin == nullptr || (ldxin >= C0 && ldxin % 4 == 0), "gn_implicit_decode: pre-sampled rows need a 16-byte aligned leading dimension");
@@ -464,7 +466,7 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
     DecodeArgs p;
     p.vol = vol; p.D = D; p.H = H; p.W = W; p.C0 = C0; p.xin = xin; p.ldxin = ldxin; p.query = query; p.Q = Q; p.m0 = m0; p.M = M;
     p.w1p = w1p; p.b1 = b1; p.s1 = s1; p.t1 = t1; p.N1 = N1; p.w2p = w2p; p.b2 = b2; p.s2 = s2; p.t2 = t2; p.N2 = N2;
-    p.w3 = w3; p.b3 = b3; p.s3 = s3; p.t3 = t3; p.OUT = OUT; p.out = out; p.ldo = ldo;
+    p.w3 = w3; p.b3 = b3; p.s3 = s3; p.t3 = t3; p.OUT = OUT; p.out = out; p.ldo = ldo; p.run_if = run_if;
     const int ldp = C0 + 4, ldq = N1 + 4;
     const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq + 8 * OUT);
     GN_REQUIRE(sh <= 160 * 1024, "gn_implicit_decode: layer widths need %zu bytes of LDS", sh);

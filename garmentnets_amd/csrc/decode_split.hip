@@ -46,7 +46,8 @@ struct DecSplitArgs {
     const float *xin; int ldxin; long long M;
     const unsigned char *wp;         // [stages][4 k-group steps][2 blocks][2 planes][64 lanes] x 16 B; step order: layer 1 (pair, k-group), layer 2
     const float *tab;                // tab1 [8][2][16] (b1'') | tab2 [8][2][1+OUT][16] (b2'', w3'') | b3', s3, t3 [3][OUT]
-    const float *xscale;             // NULL or device {s_x, 1 / s_x}: the garment's input scale (exact power of two)
+    const float *xscale;             // NULL or device {s_x, 1 / s_x, unsafe, 0}: the garment's input scale (exact power of two); unsafe != 0:
+                                     // this kernel does nothing (the caller's gated fp32 kernel computes the rows instead)
     float *out; int ldo;
 };
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
 
+    if (p.xscale && p.xscale[2] != 0.f) return;     // wave-uniform: the whole grid leaves (gn_decoder_input_scale's verdict)
     const float sx = p.xscale ? p.xscale[0] : 1.f, inv_sx = p.xscale ? p.xscale[1] : 1.f;
     // the bias entries (all of tab1, row 0 of every tab2 block) enter in the scaled units of the chain
     for (int i = tid; i < TABN; i += 256) {
@@ -289,7 +291,9 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
 
 // the garment's input scale from the per-channel sums of squares of the volume the rows are sampled from (= the statistics the last
 // conv's epilogue emitted): s = 2^k with (largest channel rms) * s in [1, 2), clamped to smax (the pack's bound that keeps the scaled
-// biases small); out[b] = {s, 1/s}
+// biases below 2^13).  When the clamp costs more than 2^4 the rows would be split below their natural scale (a checkpoint whose biases
+// dwarf weights x activations in some unit): `unsafe` = 1 sends the garment to the fp32 kernel instead, decided on the device, no
+// host synchronisation.  out[b] = {s, 1/s, unsafe, 0}
 __global__ void decoder_input_scale_kernel(const double *__restrict__ sumsq, int64_t V, int B, int C, float smax, float *__restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -305,15 +309,18 @@ __global__ void decoder_input_scale_kernel(const double *__restrict__ sumsq, int
         if (e < -100) e = -100;
         s = ldexpf(1.f, e);
     }
+    const float s0 = s;
     if (s > smax) s = smax;
-    out[2 * b] = s;
-    out[2 * b + 1] = 1.f / s;
+    out[4 * b] = s;
+    out[4 * b + 1] = 1.f / s;
+    out[4 * b + 2] = (s0 > 16.f * s) ? 1.f : 0.f;
+    out[4 * b + 3] = 0.f;
 }
 
-extern "C" int gn_decoder_input_scale(const double *sumsq, int64_t V, int B, int C, float smax, float *out2, void *stream) {
+extern "C" int gn_decoder_input_scale(const double *sumsq, int64_t V, int B, int C, float smax, float *out4, void *stream) {
     GN_REQUIRE(B >= 0 && C > 0 && V > 0 && smax > 0.f, "gn_decoder_input_scale: bad sizes");
     if (B == 0) return GN_OK;
-    hipLaunchKernelGGL(decoder_input_scale_kernel, dim3((unsigned)gn_cdiv(B, 64)), dim3(64), 0, gn_stream(stream), sumsq, V, B, C, smax, out2);
+    hipLaunchKernelGGL(decoder_input_scale_kernel, dim3((unsigned)gn_cdiv(B, 64)), dim3(64), 0, gn_stream(stream), sumsq, V, B, C, smax, out4);
     GN_LAUNCH_CHECK("gn_decoder_input_scale");
     return GN_OK;
 }

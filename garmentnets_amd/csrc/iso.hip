@@ -754,3 +754,73 @@ extern "C" int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing
     GN_LAUNCH_CHECK("gn_scale_verts");
     return GN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ mesh compaction
+// delete_invalid_verts (common/marching_cubes_util.py:38-52; eval.py / predict.py's hole head): keep the faces whose three vertices
+// are on the surface, keep the vertices those faces use (ascending raw index = np.unique order), renumber.  One flag word per index
+// i (low 32 bits: vertex i is used, high 32 bits: face i is kept), the three-kernel exclusive scan of the MC33 stage over the packed
+// pair, one scatter pass.  Deterministic; sizes come back in counts (device), outputs have room for everything.
+__global__ __launch_bounds__(256) void compact_mark_kernel(const int32_t *__restrict__ faces, const unsigned char *__restrict__ on_surface,
+                                                           int64_t F, unsigned long long *__restrict__ flags) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const int32_t a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    if (on_surface[a] && on_surface[b] && on_surface[c]) {
+        atomicOr(reinterpret_cast<unsigned *>(flags + a), 1u);
+        atomicOr(reinterpret_cast<unsigned *>(flags + b), 1u);
+        atomicOr(reinterpret_cast<unsigned *>(flags + c), 1u);
+        atomicOr(reinterpret_cast<unsigned *>(flags + f) + 1, 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned char *__restrict__ verts, int vert_bytes, const int32_t *__restrict__ faces,
+                                                              int64_t V, int64_t F, const unsigned long long *__restrict__ flags,
+                                                              const unsigned long long *__restrict__ ex, unsigned char *__restrict__ out_verts,
+                                                              int32_t *__restrict__ out_faces) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V && (flags[i] & 1ull)) {
+        const int64_t nv = (int64_t)(ex[i] & 0xffffffffull);
+        for (int k = 0; k < vert_bytes; k += 4)
+            *reinterpret_cast<uint32_t *>(out_verts + nv * vert_bytes + k) = *reinterpret_cast<const uint32_t *>(verts + i * vert_bytes + k);
+    }
+    if (i < F && (flags[i] >> 32)) {
+        const int64_t nf = (int64_t)(ex[i] >> 32);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out_faces[3 * nf + k] = (int32_t)(ex[faces[3 * i + k]] & 0xffffffffull);
+    }
+}
+
+__global__ void unpack_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts) {
+    counts[0] = (int64_t)(*total & 0xffffffffull);
+    counts[1] = (int64_t)(*total >> 32);
+}
+
+extern "C" size_t gn_mesh_compact_workspace_bytes(int64_t V, int64_t F) {
+    const size_t n = (size_t)(V > F ? V : F), nb = (n + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    return sizeof(unsigned long long) * (2 * n + nb + 2);
+}
+
+extern "C" int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, const unsigned char *on_surface, int64_t V, int64_t F,
+                               void *ws, size_t ws_bytes, void *out_verts, int32_t *out_faces, int64_t *counts, void *stream) {
+    GN_REQUIRE(V >= 0 && F >= 0 && V < (1ll << 31) && F < (1ll << 31) && vert_bytes > 0 && vert_bytes % 4 == 0, "gn_mesh_compact: bad sizes");
+    GN_REQUIRE(ws_bytes >= gn_mesh_compact_workspace_bytes(V, F), "gn_mesh_compact: workspace too small");
+    hipStream_t st = gn_stream(stream);
+    const int64_t n = V > F ? V : F;
+    if (n == 0 || F == 0 || V == 0) {
+        GN_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st), "gn_mesh_compact");
+        return GN_OK;
+    }
+    const int64_t nb = gn_cdiv(n, SCAN_ELEMS);
+    unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws), *ex = flags + n, *bsum = ex + n, *total = bsum + nb;
+    GN_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * (size_t)n, st), "gn_mesh_compact");
+    hipLaunchKernelGGL(compact_mark_kernel, dim3((unsigned)gn_cdiv(F, 256)), dim3(256), 0, st, faces, on_surface, F, flags);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, nb, total);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, ex);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)gn_cdiv(n, 256)), dim3(256), 0, st, (const unsigned char *)verts, vert_bytes, faces, V, F,
+                       flags, ex, (unsigned char *)out_verts, out_faces);
+    // counts = (vertices kept, faces kept): unpack the scan total on the device
+    hipLaunchKernelGGL(unpack_counts_kernel, dim3(1), dim3(1), 0, st, total, counts);
+    GN_LAUNCH_CHECK("gn_mesh_compact");
+    return GN_OK;
+}

@@ -122,8 +122,9 @@ class ImplicitWNFDecoder(PackedModule):
                 cache[key] = tuple(layers) + (split,)
         return cache[key]
 
-    def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None):
-        """vol_b [D][H][W][C]: the decoder's own input volume, or (with the folded `layers`) the UNet's pre-final volume"""
+    def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None, xscale=None):
+        """vol_b [D][H][W][C]: the decoder's own input volume, or (with the folded `layers`) the UNet's pre-final volume;
+        xscale: this garment's (s, 1/s) input scale for the split-operand kernel (ops.decoder_input_scale)"""
         M = out.shape[0]
         if layers is None:
             layers = self.packed() if self.fused else None
@@ -138,7 +139,9 @@ class ImplicitWNFDecoder(PackedModule):
             else:
                 s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m, out=buf[:m])
             if layers is not None and layers[3] is not None and ops.DECODE_MODE == "f16x2":
-                ops.implicit_decode_split(s, layers[3], out=out[m0:m0 + m])
+                ops.implicit_decode_split(s, layers[3], out=out[m0:m0 + m], xscale=xscale)
+                if xscale is not None:      # the garments the device marked unsafe for fp16 planes: gated fp32 twin (a no-op otherwise)
+                    ops.implicit_decode(None, layers[:3], M=m, out=out[m0:m0 + m], xin=s, run_if=xscale[2:3])
             elif layers is not None:
                 ops.implicit_decode(None, layers[:3], M=m, out=out[m0:m0 + m], xin=s)
             else:
@@ -150,17 +153,36 @@ class ImplicitWNFDecoder(PackedModule):
         B, M = query_points.shape[:2]
         q = query_points.float().contiguous()
         out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=vol.device)
+        xs = self._volume_scales(vol)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], query=q[b])
+            self._decode_rows(vol[b], out[b], query=q[b], xscale=None if xs is None else xs[b])
         return out
+
+    def _volume_scales(self, vol, stats=None, layers=None):
+        """(B, 2) input scales of the split-operand decoder kernel for the channel-last volume the rows are sampled from, or None when
+        that kernel is not the one that runs.  stats: the (sum, sumsq, V) its producer emitted; else one gn_channel_stats pass over the
+        volume, remembered for the same tensor (the reference's chunk loop calls the decoder 8 times per garment on one volume)."""
+        if layers is None:
+            layers = self.packed() if self.fused else None
+        if layers is None or layers[3] is None or ops.DECODE_MODE != "f16x2":
+            return None
+        if stats is None:
+            key = (vol.data_ptr(), vol._version, tuple(vol.shape))
+            cached = self.__dict__.get("_vol_stats")
+            if cached is None or cached[0] != key:
+                cached = (key, ops.channel_stats(vol))
+                self.__dict__["_vol_stats"] = cached
+            stats = cached[1]
+        return ops.decoder_input_scale(stats[1], stats[2], layers[3].smax)
 
     def decode_lattice(self, features_grid, Q):
         """All (Q,Q,Q) lattice queries of predict.py:145-157 without materialising them -> (B,Q,Q,Q[,out])"""
         vol = to_channel_last(features_grid)
         B = vol.shape[0]
         out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
+        xs = self._volume_scales(vol)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], Q=Q)
+            self._decode_rows(vol[b], out[b], Q=Q, xscale=None if xs is None else xs[b])
         return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
 
     def run_on(self, unet3d_result, query_points=None, Q=0):
@@ -175,15 +197,18 @@ class ImplicitWNFDecoder(PackedModule):
             return self.decode_lattice(vol, Q) if query_points is None else self(vol, query_points)
         vol = unet3d_result.pre_final
         B = vol.shape[0]
+        xs = None
+        if layers[3] is not None and ops.DECODE_MODE == "f16x2":
+            xs = unet3d_result.input_scales(layers[3].smax)
         if query_points is None:
             out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
             for b in range(B):
-                self._decode_rows(vol[b], out[b], Q=Q, layers=layers)
+                self._decode_rows(vol[b], out[b], Q=Q, layers=layers, xscale=None if xs is None else xs[b])
             return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
         q = query_points.float().contiguous()
         out = torch.empty((B, q.shape[1], self.out_channels), dtype=torch.float32, device=vol.device)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], query=q[b], layers=layers)
+            self._decode_rows(vol[b], out[b], query=q[b], layers=layers, xscale=None if xs is None else xs[b])
         return out
 
 
@@ -196,13 +221,25 @@ class UNetResult(dict):
     """unet3d_forward's result: {'out_feature_volume': (B,128,D,H,W)} as in the reference, except that the 128-channel volume is
     only materialised (one gn_linear over all voxels) if somebody actually reads it; the decoders do not (see folded_pack)."""
 
-    def __init__(self, pre_final, final_conv):
+    def __init__(self, pre_final, final_conv, pre_stats=None):
         super().__init__()
         self.pre_final, self.final_conv = pre_final, final_conv          # [B][D][H][W][f_maps[0]] channel-last
+        self.pre_stats = pre_stats                                       # (sum, sumsq, V) of pre_final from the last conv's epilogue, or None
+        self._scales = {}                                                # smax -> (B, 2) decoder input scales
+
+    def input_scales(self, smax):
+        """(B, 2) run-time input scales (s, 1/s) of the split-operand decoder kernel for this volume (ops.decoder_input_scale)"""
+        if smax not in self._scales:
+            if self.pre_stats is None:
+                self.pre_stats = ops.channel_stats(self.pre_final)
+            self._scales[smax] = ops.decoder_input_scale(self.pre_stats[1], self.pre_stats[2], smax)
+        return self._scales[smax]
 
     def select(self, b0, b1):
         """the same result for garments b0..b1-1 (predict.py slices out_feature_volume[[i]] per sample)"""
-        sub = UNetResult(self.pre_final[b0:b1], self.final_conv)
+        st = None if self.pre_stats is None else (self.pre_stats[0][b0:b1], self.pre_stats[1][b0:b1], self.pre_stats[2])
+        sub = UNetResult(self.pre_final[b0:b1], self.final_conv, st)
+        sub._scales = {k: v[b0:b1] for k, v in self._scales.items()}
         if dict.__contains__(self, "out_feature_volume"):
             dict.__setitem__(sub, "out_feature_volume", dict.__getitem__(self, "out_feature_volume")[b0:b1])
         return sub
@@ -229,6 +266,29 @@ class UNetResult(dict):
 
     def get(self, k, default=None):
         return self[k] if k in self else default
+
+    # the rest of the Mapping surface sees the reference's one-key dict too (CPython's dict(u3) / copy / len fast paths bypass keys())
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return 1
+
+    def copy(self):
+        self._materialise()
+        return dict(dict.items(self))
+
+    def __reduce__(self):
+        self._materialise()
+        return (dict, (dict(dict.items(self)),))
+
+    def __repr__(self):
+        return "UNetResult(out_feature_volume=%s)" % ("<lazy>" if not dict.__contains__(self, "out_feature_volume") else tuple(dict.__getitem__(self, "out_feature_volume").shape),)
 
 
 class ConvImplicitWNFPipeline(nn.Module):
@@ -283,8 +343,8 @@ class ConvImplicitWNFPipeline(nn.Module):
     def unet3d_forward(self, pointnet2_result):
         in_feature_volume = self.volume_agg(pointnet2_result["nocs_data"])
         net = self.unet_3d.abstract_3d_unet
-        pre = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True)
-        return UNetResult(pre, net.final_conv)       # ['out_feature_volume'] materialises the reference's tensor on demand
+        pre, st = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True, return_stats=True)
+        return UNetResult(pre, net.final_conv, st)   # ['out_feature_volume'] materialises the reference's tensor on demand
 
     def volume_decoder_forward(self, unet3d_result, query_points):
         out = self.volume_decoder.run_on(unet3d_result, query_points)

@@ -113,6 +113,57 @@ def segment_max(h, slot_src, M, S):
     return out
 
 
+class SaFusedPack:
+    """weights / epilogue tables of gn_sa_fused for one edge MLP [cin+3, n1, n2, n3]"""
+
+    def __init__(self, w1p, w2p, w3p, tab, cin, dims):
+        self.w1p, self.w2p, self.w3p, self.tab, self.cin, self.dims = w1p, w2p, w3p, tab, int(cin), tuple(int(v) for v in dims)
+        self.cout = self.dims[2]
+        self.macs_per_edge = (self.cin + 3) * self.dims[0] + self.dims[0] * self.dims[1] + self.dims[1] * self.dims[2]
+
+    def to(self, device):
+        return SaFusedPack(self.w1p.to(device), self.w2p.to(device), self.w3p.to(device), self.tab.to(device), self.cin, self.dims)
+
+
+def sa_fused_supported(cin, dims):
+    return len(dims) == 3 and bool(_lib.load().gn_sa_fused_supported(int(cin), int(dims[0]), int(dims[1]), int(dims[2])))
+
+
+def pack_sa_fused(layers):
+    """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)): Linear weight (n, k) / bias and the folded eval-BatchNorm scale / shift (or
+    None) of the three blocks of a PointConv local_nn; w1 is (n1, cin + 3) -> SaFusedPack.  A-fragment order of csrc/sa_fused.hip:
+    Wp[nb][kb][qq][lane = 32 h + r][i] = W[32 nb + r][32 kb + 8 qq + 4 h + i] (zero beyond k); tables in accumulator-register order:
+    register q of lane half h of block nb is unit 32 nb + 8 (q >> 2) + (q & 3) + 4 h."""
+    ar = torch.arange
+    packs, tabs, dims = [], [], []
+    for w, b, sc, sh in layers:
+        w = w.detach().float().cpu()
+        n, k = w.shape
+        assert n % 32 == 0
+        kb_n = (((k + 7) // 8 * 8) + 31) // 32
+        wz = torch.zeros((n, kb_n * 32), dtype=torch.float32)
+        wz[:, :k] = w
+        nb, kb, qq, h, r, i = torch.meshgrid(ar(n // 32), ar(kb_n), ar(4), ar(2), ar(32), ar(4), indexing="ij")
+        packs.append(wz[32 * nb + r, 32 * kb + 8 * qq + 4 * h + i].contiguous())                 # [nb][kb][qq][h][r][4]
+        nbt, ht, q = torch.meshgrid(ar(n // 32), ar(2), ar(16), indexing="ij")
+        u = 32 * nbt + 8 * (q >> 2) + (q & 3) + 4 * ht                                            # [nb][2][16]
+        one = lambda v, fill: (torch.full((n,), fill) if v is None else v.detach().float().cpu())
+        tabs.append(torch.stack((one(b, 0.0)[u], one(sc, 1.0)[u], one(sh, 0.0)[u]), dim=2).reshape(-1))   # [nb][2][3][16]
+        dims.append(n)
+    cin = layers[0][0].shape[1] - 3
+    return SaFusedPack(packs[0], packs[1], packs[2], torch.cat(tabs).contiguous(), cin, dims)
+
+
+def sa_fused(x, pos, centre_idx, nbr, cnt, pack, self_loops=True):
+    """fps centres + ball-query table -> [M][n3] set-abstraction features (PointConv(local_nn, max) in one kernel, csrc/sa_fused.hip)"""
+    M, K = nbr.shape
+    out = new_rows(M, pack.cout, pos.device)
+    ldx = 0 if x is None else rows_view(x)[1]
+    _lib.call("gn_sa_fused", _p(x), ldx, pack.cin, _p(_chk(pos, torch.float32, "pos")), _p(centre_idx), _p(nbr), _p(cnt), M, K, 1 if self_loops else 0,
+              _p(pack.w1p), _p(pack.w2p), _p(pack.w3p), _p(pack.tab), pack.dims[0], pack.dims[1], pack.dims[2], _p(out), out.stride(0), _stream())
+    return out
+
+
 def global_max_pool(h, ptr, B):
     C = h.shape[1]
     out = new_rows(B, C, h.device)
@@ -343,9 +394,10 @@ def pack_kpair(w):
     return w.detach().float().reshape(n, k // 16, 2, 8).permute(1, 0, 2, 3).contiguous()
 
 
-def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=None):
+def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=None, run_if=None):
     """vol_b [D][H][W][C0]; layers = ((w1p,b1,s1,t1,N1), (w2p,b2,s2,t2,N2), (w3,b3,s3,t3,OUT)) -> out [M][OUT].
-    xin: optional pre-sampled rows [M][C0] (then only the MLP runs)."""
+    xin: optional pre-sampled rows [M][C0] (then only the MLP runs).  run_if: optional device float; the launch is a no-op unless it
+    is non-zero (the fp32 twin of a gated implicit_decode_split call)."""
     (w1p, b1, s1, t1, N1), (w2p, b2, s2, t2, N2), (w3, b3, s3, t3, OUT) = layers
     if xin is not None:
         D = H = W = 0
@@ -360,7 +412,7 @@ def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=
     if out is None:
         out = torch.empty((M, OUT), dtype=torch.float32, device=(xin if xin is not None else vol_b).device)
     _lib.call("gn_implicit_decode", _p(vol_b), D, H, W, C0, _p(xin), ldxin, _p(query), int(Q), int(m0), int(M), _p(w1p), _p(b1), _p(s1), _p(t1), N1,
-              _p(w2p), _p(b2), _p(s2), _p(t2), N2, _p(w3), _p(b3), _p(s3), _p(t3), OUT, _p(out), rows_view(out)[1], _stream())
+              _p(w2p), _p(b2), _p(s2), _p(t2), N2, _p(w3), _p(b3), _p(s3), _p(t3), OUT, _p(out), rows_view(out)[1], _p(run_if), _stream())
     return out
 
 
@@ -369,18 +421,20 @@ DECODE_MODE = _env_choice("GARMENTNETS_DECODE_MODE", "f16x2", ("f16x2", "fp32"))
 
 
 class DecodeSplitPack:
-    """weights / epilogue tables of gn_implicit_decode_split for one [128, 256, 256, OUT] decoder"""
+    """weights / epilogue tables of gn_implicit_decode_split for one [128 | 32, 256, 256, OUT] decoder; smax: upper bound for the run-time
+    input scale (keeps the scaled biases small, see pack_decode_split)"""
 
-    def __init__(self, wpack, tab, inv1, inv2, out_channels):
-        self.wpack, self.tab, self.inv1, self.inv2, self.out_channels = wpack, tab, float(inv1), float(inv2), int(out_channels)
+    def __init__(self, wpack, tab, smax, out_channels):
+        self.wpack, self.tab, self.smax, self.out_channels = wpack, tab, float(smax), int(out_channels)
 
     def to(self, device):
-        return DecodeSplitPack(self.wpack.to(device), self.tab.to(device), self.inv1, self.inv2, self.out_channels)
+        return DecodeSplitPack(self.wpack.to(device), self.tab.to(device), self.smax, self.out_channels)
 
 
-def _pow2_scale(w):
-    m = float(w.abs().max())
-    return 2.0 ** (-math.floor(math.log2(m))) if (m > 0 and math.isfinite(m)) else 1.0
+def _pow2_floor_inv(m):
+    """per-row power of two r with r * m in [1, 2) (1 where m is 0 / non-finite); m: fp64 tensor"""
+    ok = torch.isfinite(m) & (m > 0)
+    return torch.where(ok, torch.exp2(-torch.floor(torch.log2(torch.where(ok, m, torch.ones_like(m))))), torch.ones_like(m))
 
 
 def _d_unit(q, h):
@@ -391,28 +445,39 @@ def _d_unit(q, h):
 def pack_decode_split(layers):
     """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)) with w1 (256,128), w2 (256,256), w3 (OUT,256) fp32, s/t = folded
     BatchNorm scale/shift or None -> DecodeSplitPack.  The BatchNorm affine of hidden layer i is folded into layer i+1
-    (W' = W diag(s), b' = b + W t, in fp64).  Weight stages: [24][4 k-groups][2 blocks][2 planes][64 lanes][8 fp16]; layer 2's k
-    order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip).  w1 may be (256, 32):
-    the first layer with the UNet's final 1x1x1 convolution folded in (ImplicitWNFDecoder.folded_pack)."""
+    (W' = W diag(s), b' = b + W t, in fp64).  Every hidden unit j carries a static power-of-two scale r_j (its weight row's maximum
+    scaled into [1, 2)): the kernel keeps hidden activations in those units (r_j * s_x * h_j, s_x = the garment's run-time input scale)
+    and 1 / r_j is folded into the next layer's column j -- all exact.  Weight stages: [24][4 k-groups][2 blocks][2 planes][64 lanes]
+    [8 fp16]; layer 2's k order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip).  w1 may
+    be (256, 32): the first layer with the UNet's final 1x1x1 convolution folded in (ImplicitWNFDecoder.folded_pack)."""
     (w1, b1, s1, t1), (w2, b2, s2, t2), (w3, b3, s3, t3) = layers
     dd = lambda v, n, fill: (torch.full((n,), fill, dtype=torch.float64) if v is None else v.detach().double().cpu())
     w1, w2, w3 = w1.detach().double().cpu(), w2.detach().double().cpu(), w3.detach().double().cpu()
     out_c = w3.shape[0]
     assert w1.shape in ((256, 128), (256, 32)) and w2.shape == (256, 256) and w3.shape[1] == 256 and 1 <= out_c <= 4
     k0g = w1.shape[1] // 16                                                                       # 16-deep k-groups of layer 1
-    b2f = (dd(b2, 256, 0.0) + w2 @ dd(t1, 256, 0.0)).float()
-    w2 = (w2 * dd(s1, 256, 1.0)[None, :]).float()
+    b2f = dd(b2, 256, 0.0) + w2 @ dd(t1, 256, 0.0)
+    w2 = w2 * dd(s1, 256, 1.0)[None, :]
     b3f = (dd(b3, out_c, 0.0) + w3 @ dd(t2, 256, 0.0)).float()
-    w3 = (w3 * dd(s2, 256, 1.0)[None, :]).float()
-    w1, b1f = w1.float(), dd(b1, 256, 0.0).float()
-    sc1, sc2 = _pow2_scale(w1), _pow2_scale(w2)
+    w3 = w3 * dd(s2, 256, 1.0)[None, :]
+    b1f = dd(b1, 256, 0.0)
+    # per-unit scales (exact powers of two); a weight or bias that leaves fp32's range through them would be a broken checkpoint anyway
+    r1 = _pow2_floor_inv(w1.abs().amax(dim=1))
+    w1s, b1s = (w1 * r1[:, None]).float(), (b1f * r1).float()
+    w2 = w2 / r1[None, :]
+    r2 = _pow2_floor_inv(w2.abs().amax(dim=1))
+    w2s, b2s = (w2 * r2[:, None]).float(), (b2f * r2).float()
+    w3s = (w3 / r2[None, :]).float()
+    # run-time input scale s_x <= smax keeps every scaled bias below 2^13 (hidden values = accumulator + bias stay inside fp16)
+    bmax = max(float(b1s.abs().max()), float(b2s.abs().max()))
+    smax = 2.0 ** 60 if not (bmax > 0 and math.isfinite(bmax)) else min(2.0 ** 60, 2.0 ** math.floor(math.log2(8192.0 / bmax)))
     ar = torch.arange
     bp, g1, blk, h, r, i = torch.meshgrid(ar(4), ar(k0g), ar(2), ar(2), ar(32), ar(8), indexing="ij")
-    a1 = (w1 * sc1)[32 * (2 * bp + blk) + r, 16 * g1 + 8 * h + i]                                # [pair][k-group][blk][h][r][i]
+    a1 = w1s[32 * (2 * bp + blk) + r, 16 * g1 + 8 * h + i]                                       # [pair][k-group][blk][h][r][i]
     bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(4), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
     g2 = 4 * kq + kg
     q = 8 * (g2 & 1) + i
-    a2 = (w2 * sc2)[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]
+    a2 = w2s[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]
 
     def planes(a):                                   # [..steps..][blk][h][r][i] -> [stage][4 steps][blk][plane][h][r][i]
         p1 = a.to(torch.float16)
@@ -424,19 +489,30 @@ def pack_decode_split(layers):
     assert wpack.numel() * 2 == (k0g + 16) * 16384
     nb, hh, qq = torch.meshgrid(ar(8), ar(2), ar(16), indexing="ij")
     u = 32 * nb + (qq & 3) + 8 * (qq >> 2) + 4 * hh                                               # [8][2][16]
-    tab1 = b1f[u]
-    tab2 = torch.stack([b2f[u]] + [w3[o][u] for o in range(out_c)], dim=2)                        # [8][2][1+OUT][16]
+    tab1 = b1s[u]
+    tab2 = torch.stack([b2s[u]] + [w3s[o][u] for o in range(out_c)], dim=2)                       # [8][2][1+OUT][16]
     tail = torch.stack((b3f, dd(s3, out_c, 1.0).float(), dd(t3, out_c, 0.0).float()))
     tab = torch.cat((tab1.reshape(-1), tab2.reshape(-1), tail.reshape(-1))).float().contiguous()
-    return DecodeSplitPack(wpack, tab, 1.0 / sc1, 1.0 / sc2, out_c)
+    return DecodeSplitPack(wpack, tab, smax, out_c)
 
 
-def implicit_decode_split(xin, pack, out=None):
-    """pre-sampled rows xin [M][128 | 32] -> out [M][OUT] through the [128 | 32, 256, 256, OUT] decoder on the 16-bit matrix cores"""
+def decoder_input_scale(sumsq, V, smax):
+    """per-garment input scale of gn_implicit_decode_split from the per-(sample, channel) sums of squares of the sampled volume
+    -> float32 [B][4] = (s, 1/s, unsafe, 0); unsafe = 1: the garment goes to the gated fp32 kernel (decided on the device)"""
+    B, C = sumsq.shape
+    out = torch.empty((B, 4), dtype=torch.float32, device=sumsq.device)
+    _lib.call("gn_decoder_input_scale", _p(_chk(sumsq, torch.float64, "sumsq")), int(V), B, C, float(smax), _p(out), _stream())
+    return out
+
+
+def implicit_decode_split(xin, pack, out=None, xscale=None):
+    """pre-sampled rows xin [M][128 | 32] -> out [M][OUT] through the [128 | 32, 256, 256, OUT] decoder on the 16-bit matrix cores.
+    xscale: the garment's (s, 1/s, unsafe, 0) row of decoder_input_scale (None: unscaled rows -- fine for O(1) inputs only); with
+    unsafe != 0 the launch is a no-op and the caller's implicit_decode(..., run_if=xscale[2:3]) fills `out`"""
     M, C0 = xin.shape
     if out is None:
         out = torch.empty((M, pack.out_channels), dtype=torch.float32, device=xin.device)
-    _lib.call("gn_implicit_decode_split", _p(xin), rows_view(xin)[1], int(M), _p(pack.wpack), _p(pack.tab), pack.inv1, pack.inv2,
+    _lib.call("gn_implicit_decode_split", _p(xin), rows_view(xin)[1], int(M), _p(pack.wpack), _p(pack.tab), _p(xscale),
               C0, 256, 256, pack.out_channels, _p(out), rows_view(out)[1], _stream())
     return out
 
@@ -485,6 +561,24 @@ def scale_verts(verts_vox, spacing):
     out = torch.empty_like(verts_vox)
     _lib.call("gn_scale_verts", _p(verts_vox), verts_vox.shape[0], float(spacing), _p(out), _stream())
     return out
+
+
+def mesh_compact(verts, faces, on_surface):
+    """delete_invalid_verts on the GPU -> (verts' (V',3) same dtype, faces' (F',3) int32); one host synchronisation for the two sizes"""
+    assert verts.dim() == 2 and verts.shape[1] == 3 and verts.dtype in (torch.float32, torch.float64)
+    verts = verts.contiguous()
+    faces = _chk(faces.to(torch.int32).contiguous(), torch.int32, "faces")
+    flag = on_surface.to(torch.uint8).contiguous()
+    V, F = verts.shape[0], faces.shape[0]
+    if flag.numel() != V:
+        raise ValueError("is_vert_on_surface must have one entry per vertex")
+    nbytes = _lib.load().gn_mesh_compact_workspace_bytes(V, F)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=verts.device)
+    out_v, out_f = torch.empty_like(verts), torch.empty_like(faces)
+    counts = torch.empty(2, dtype=torch.int64, device=verts.device)
+    _lib.call("gn_mesh_compact", _p(verts), verts.element_size() * 3, _p(faces), _p(flag), V, F, _p(ws), nbytes, _p(out_v), _p(out_f), _p(counts), _stream())
+    nv, nf = [int(c) for c in counts.cpu()]
+    return out_v[:nv], out_f[:nf]
 
 
 # ------------------------------------------------------------------------------------------------ evaluation helpers

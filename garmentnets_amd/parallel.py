@@ -33,6 +33,17 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_batch(global_batch, n_points, seed, rank, world):
+    """this rank's contiguous shard of the seeded GLOBAL batch of synthetic garments (BASELINE config[3]: 128 garments over 8 GPUs):
+    -> (Batch on the host with batch ids restarting at 0, (lo, hi)).  Garment g of the global batch depends on (seed, g) only, so the
+    concatenation of the shards over the ranks IS synthetic_cloud(global_batch, n_points, seed) -- tests/test_parallel_cpu.py."""
+    from . import synthetic
+    from .batch import Batch
+    lo, hi = shard_range(global_batch, rank, world)
+    x, pos, batch = synthetic.synthetic_cloud(hi - lo, n_points, seed=seed, first=lo)
+    return Batch(sizes=[n_points] * (hi - lo), x=x, pos=pos, batch=batch), (lo, hi)
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

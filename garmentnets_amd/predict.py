@@ -33,19 +33,50 @@ def nan_placeholder(device):
                 volume_gradient_magnitude=torch.full((1,), float("nan"), device=device), warp_field=nan3.clone())
 
 
+_FALLBACKS = {"count": 0}
+
+
 def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
                   use_hole_prediction=False, auto_level=False):
-    """-> list (one per garment) of dicts of device tensors."""
+    """-> list (one per garment) of dicts of device tensors.
+
+    Arithmetic: the default f16x2 operand split (ops.CONV_MODE / ops.DECODE_MODE) covers fp32's range through power-of-two scales
+    (per output channel, per sample, per hidden unit; csrc/unet_split.hip, csrc/decode_split.hip).  What those cannot cover -- a value
+    beyond fp16's range in the scaled units -- surfaces as NaN in the WNF volume, never as a wrong finite number; such a batch is
+    re-run here with the fp32-MFMA kernels (one warning; the count is in predict._FALLBACKS)."""
+    from . import ops
+    split = ops.CONV_MODE != ops.CONV_FP32 or ops.DECODE_MODE != "fp32"
+    results, bad = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, split)
+    if split and (results is None or bool(bad)):
+        import warnings
+        _FALLBACKS["count"] += 1
+        if _FALLBACKS["count"] == 1:
+            warnings.warn("garmentnets_amd: NaN in the WNF volume under the split-operand arithmetic (a value left fp16's range, or the input "
+                          "holds NaN): re-running the batch with the fp32 kernels")
+        saved = (ops.CONV_MODE, ops.DECODE_MODE)
+        try:
+            ops.CONV_MODE, ops.DECODE_MODE = ops.CONV_FP32, "fp32"
+            results, _ = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, False)
+        finally:
+            ops.CONV_MODE, ops.DECODE_MODE = saved
+    return results
+
+
+def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
+    """-> (results, device bool: the WNF holds a NaN); stop_on_nan: -> (None, True) before the per-garment tail when it does"""
     with torch.no_grad():
         pointnet2_result = model.pointnet2_forward(batch)
         unet3d_result = model.unet3d_forward(pointnet2_result)
         nocs_data = pointnet2_result["nocs_data"]
         B = nocs_data.num_graphs
         wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
+        bad = torch.isnan(wnf_all).any()             # read by the caller after the batch's own host synchronisation
         ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
         results = []
         # iso-surfaces of the whole batch with one host synchronisation (fixed level); auto_level needs each volume's range first
         meshes = None if auto_level else mcu.wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level, gradient_sigma, gradient_direction)
+        if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
+            return None, True
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
         bins = model.pointnet2_nocs.nocs_bins
         glog_all = pointnet2_result["global_logits"].reshape(B, bins, 3)
@@ -88,7 +119,7 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
                        pred_nocs_grip_point=grip_nocs[b] if grip_idx is not None else nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
                        global_feature=pointnet2_result["global_feature"][b])
             results.append(res)
-        return results
+        return results, bad
 
 
 def to_host(res):

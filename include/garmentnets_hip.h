@@ -76,6 +76,19 @@ int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t
 int gn_segment_max(const float *in, int ldi, const int32_t *slot_src, int M, int S, int C, float *out, int ldo,
                    void *stream);
 
+/* Set abstraction in ONE kernel: grouping gather -> 3-layer edge MLP (Linear -> ReLU -> eval-BatchNorm affine per layer, exact fp32
+ * products on the matrix cores) -> segmented max, no edge tensor in HBM.  replaces PointConv(local_nn, aggr='max', add_self_loops)
+ * on the radius graph -- components/pointnet2.py:20,31 (= gn_sa_gather + 3 x gn_linear + gn_segment_max, which remain for other MLP
+ * shapes).  nbr/cnt: gn_ball_query's table (K <= 64, valid entries first); self_loops: PyG's bipartite quirk (centre i also receives
+ * point i of the whole cloud; table entries equal to the centre's own index are dropped).  w1p/w2p/w3p/tab: garmentnets_amd.ops.
+ * pack_sa_fused (A fragments [N/32][K blocks][4][64 lanes] x 16 B; per-unit bias | scale | shift in accumulator-register order).
+ * Instantiated for the shipped edge MLPs [3+3,64,64,128] and [128+3,128,128,256] (gn_sa_fused_supported).  out [M][ldo]: max over
+ * the centre's edges, 0 for a centre without edges. */
+int gn_sa_fused_supported(int C, int N1, int N2, int N3);
+int gn_sa_fused(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr, const int32_t *cnt,
+                int M, int K, int self_loops, const float *w1p, const float *w2p, const float *w3p, const float *tab, int N1, int N2,
+                int N3, float *out, int ldo, void *stream);
+
 /* out[b][ch] = max over rows ptr[b]..ptr[b+1].  replaces PyG global_max_pool -- components/pointnet2.py:49. */
 int gn_global_max_pool(const float *in, int ldi, const int32_t *ptr, int B, int C, float *out, int ldo, void *stream);
 
@@ -192,11 +205,13 @@ int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const floa
  * predict.py:145-157,184-187.  Activations stay in LDS; w1p / w2p are k-pair-major packs Wp[k/2][n][2] of the Linear
  * weights W[n][k]; w3 is [OUT][N2] row-major; (s*, t*) are the folded eval-BatchNorm scale/shift (NULL = no BN).
  * If xin != NULL the rows xin[M][C0] (ld ldxin) are used instead of sampling (two-kernel form: gn_trilinear_sample first).
- * Constraints: C0 % 32 == 0, N1 and N2 multiples of 256, OUT <= 4 (otherwise use gn_trilinear_sample + gn_linear). */
+ * Constraints: C0 % 32 == 0, N1 and N2 multiples of 256, OUT <= 4 (otherwise use gn_trilinear_sample + gn_linear).
+ * run_if: NULL, or a device float: the launch does nothing unless *run_if != 0 (pairs with gn_implicit_decode_split, which skips
+ * the garments gn_decoder_input_scale marks unsafe for the fp16 planes: the choice is made on the device, without a host sync). */
 int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
                        const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
                        const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
-                       const float *s3, const float *t3, int OUT, float *out, int ldo, void *stream);
+                       const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Isosurface.
@@ -228,14 +243,32 @@ int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vo
  * surface decoder (mc_verts.astype(np.float32)). */
 int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *verts_out, void *stream);
 
+/* Mesh compaction = delete_invalid_verts (common/marching_cubes_util.py:38-52; the hole-prediction head of predict.py:202-209 and
+ * eval.py:39): keep the faces whose three vertices are flagged on_surface, keep the vertices those faces use in ascending raw index
+ * (np.unique order), renumber the faces.  verts: [V][3] of vert_bytes / 3 byte scalars (12 = float32, 24 = float64); faces [F][3]
+ * int32; on_surface [V] bytes (0 / non-0).  out_verts / out_faces must hold V / F rows; counts (device int64[2]) = kept (V', F'). */
+size_t gn_mesh_compact_workspace_bytes(int64_t V, int64_t F);
+int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, const unsigned char *on_surface, int64_t V, int64_t F,
+                    void *ws, size_t ws_bytes, void *out_verts, int32_t *out_faces, int64_t *counts, void *stream);
+
 /* The decoder MLP of gn_implicit_decode for the shipped shape [128, 256, 256, OUT<=4] on the 16-bit matrix cores: fp32 operands
  * split into two fp16 planes (3 MFMA products per fp32 product, fp32 accumulation -- the f16x2 arithmetic of
  * gn_conv3d_gcr_split), activations chained through registers, weights streamed through an LDS ring
  * (csrc/decode_split.hip).  xin: pre-sampled rows [M][ldxin] (gn_trilinear_sample); wpack / tab: weight stages and epilogue
- * tables from garmentnets_amd.ops.pack_decode_split; inv1 / inv2: the exact powers of two undoing the weight scales.
+ * tables from garmentnets_amd.ops.pack_decode_split (per-hidden-unit power-of-two weight scales folded in); xscale: NULL or a
+ * device record {s, 1/s, unsafe, 0} from gn_decoder_input_scale -- rows and biases are multiplied by s, the output sum by 1/s (exact:
+ * ReLU is positively homogeneous), so un-normalised inputs of any magnitude are split at O(1); unsafe != 0: the launch does nothing
+ * (run gn_implicit_decode with run_if = &xscale[2] right after it).  A hidden value beyond fp16's range in the
+ * scaled units reaches the output as NaN (never as a wrong finite number); callers re-run such a batch with gn_implicit_decode.
  * replaces the three Linear/ReLU/BatchNorm1d blocks of ImplicitWNFDecoder.forward -- networks/conv_implicit_wnf.py:128-149. */
-int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, float inv1, float inv2,
+int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                              int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream);
+
+/* Input scale of gn_implicit_decode_split for B garments from the per-(sample, channel) sums of squares [B][C] (fp64) of the volume
+ * the rows are sampled from (V voxels per channel; the statistics gn_conv3d_gcr* emit): s = 2^k with (largest channel rms) * s in
+ * [1, 2), clamped to smax (pack_decode_split: keeps the scaled biases below 2^13).  out4: [B][4] = {s, 1/s, unsafe, 0}; unsafe = 1
+ * when the clamp costs more than 2^4 (biases dwarf weights x activations: the fp16 planes would lose fp32-class accuracy). */
+int gn_decoder_input_scale(const double *sumsq, int64_t V, int B, int C, float smax, float *out4, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Widening: evaluation helpers.

@@ -303,7 +303,7 @@ def test_degenerate_sizes():
     assert e.shape == (0, 4, 8, 8, 32)
     with pytest.raises(ValueError):
         ops.conv3d_gcr_split(torch.zeros(1, 4, 8, 8, 16, device=DEV), None, torch.ones(1, 16, device=DEV), torch.zeros(1, 16, device=DEV),
-                             ops.SplitPack(pk.tensor, 7, 1.0), 32)
+                             ops.SplitPack(pk.tensor, 7, pk.out_scale), 32)
     raw = [(torch.randn(256, 32), torch.randn(256), None, None), (torch.randn(256, 256), torch.randn(256), None, None), (torch.randn(1, 256), torch.randn(1), None, None)]
     dp = ops.pack_decode_split(raw).to(DEV)
     assert ops.implicit_decode_split(ops.new_rows(0, 32, DEV), dp).shape == (0, 1)
@@ -641,6 +641,83 @@ def test_decoder_split_against_fp64(out_ch, M, bn, k0):
     assert e_split <= max(2 * e_f32, 2e-6) and e_split <= 2e-5
 
 
+@pytest.mark.parametrize("k0", [32, 128])
+@pytest.mark.parametrize("case", ["x=1e5", "x=1e3", "x=1e-3", "x=1e-6", "w1 row x1000", "w2 rows x1e-4", "w1 x1e-3 all"])
+def test_decoder_split_range_contract(case, k0):
+    """the decoder's input is the UN-normalised ReLU output of the last conv, its hidden layers are not normalised either: inputs from
+    1e-6 to 1e5 and heavy-tailed / tiny weight rows must keep fp32-class accuracy (run-time input scale from the volume statistics +
+    static per-unit scales, csrc/decode_split.hip).  Error relative to each output's own scale, against fp64, next to the fp32 kernel."""
+    g = torch.Generator().manual_seed(k0 + len(case))
+    M, dims = 5000, [k0, 256, 256, 3]
+    mag = float(case[2:]) if case.startswith("x=") else 1.0
+    x = torch.relu(torch.randn(M, k0, generator=g)) * mag                   # ReLU outputs, like the pre-final volume
+    raw, h = [], x.double()
+    for i in range(3):
+        w = torch.randn(dims[i + 1], dims[i], generator=g) * (2.0 / dims[i]) ** 0.5
+        if case == "w1 row x1000" and i == 0:
+            w[5] *= 1000.0
+        if case == "w2 rows x1e-4" and i == 1:
+            w[::2] *= 1e-4
+        if case == "w1 x1e-3 all" and i == 0:
+            w *= 1e-3
+        b = torch.randn(dims[i + 1], generator=g) * 0.1 * (mag if i == 0 else 1.0)
+        sc, sh = torch.rand(dims[i + 1], generator=g) + 0.5, torch.randn(dims[i + 1], generator=g) * 0.1
+        raw.append((w, b, sc, sh))
+        h = torch.relu(h @ w.double().t() + b.double()) * sc.double() + sh.double()
+    xin = ops.new_rows(M, k0, DEV)
+    xin.copy_(x.to(DEV))
+    pack = ops.pack_decode_split(raw).to(DEV)
+    sumsq = (x.double() ** 2).sum(dim=0, keepdim=True).to(DEV)
+    xs = ops.decoder_input_scale(sumsq, M, pack.smax)
+    assert float(torch.log2(xs[0, 0])) == round(float(torch.log2(xs[0, 0]))) and float(xs[0, 0] * xs[0, 1]) == 1.0
+    dv = lambda t: None if t is None else t.to(DEV)
+    layers = tuple((ops.pack_kpair(w).to(DEV) if i < 2 else w.contiguous().to(DEV), b.to(DEV), dv(sc), dv(sh), dims[i + 1]) for i, (w, b, sc, sh) in enumerate(raw))
+    out = ops.implicit_decode_split(xin, pack, xscale=xs[0])
+    ops.implicit_decode(None, layers, M=M, xin=xin, out=out, run_if=xs[0, 2:3])      # the gated fp32 twin: runs only for `unsafe` garments
+    out = out.cpu().double()
+    unsafe = bool(xs[0, 2] != 0)
+    out32 = ops.implicit_decode(None, layers, M=M, xin=xin).cpu().double()
+    if unsafe:      # biases dwarf weights x activations somewhere (x = 1e-6 next to O(0.1) biases, tiny weight rows): the device sent
+        assert torch.equal(out, out32)      # the garment to the fp32 kernel -- same bits as calling it directly
+    scale = h.abs().amax(dim=0).clamp_min(1e-30)
+    e16, e32 = ((out - h).abs().amax(dim=0) / scale).max().item(), ((out32 - h).abs().amax(dim=0) / scale).max().item()
+    print(f"decoder [{k0},256,256,3] {case}: input scale 2^{float(torch.log2(xs[0, 0])):.0f}{' (unsafe -> fp32 kernel)' if unsafe else ''}, rel err split {e16:.2e}, fp32-MFMA {e32:.2e}")
+    assert torch.isfinite(out).all() and e16 <= max(2 * e32, 3e-6)
+
+
+def test_predict_falls_back_to_fp32_on_nan(monkeypatch):
+    """a NaN in the WNF volume under the split-operand arithmetic (the only way a range violation can surface) makes predict_batch re-run
+    the batch with the fp32 kernels"""
+    from garmentnets_amd import predict as PR
+    hp = S.default_hparams(grid=16, reduce_method="max")
+    model = _model(hp, 3)
+    x, pos, batch = S.synthetic_cloud(2, 1500, seed=5)
+    data = Batch(sizes=[1500, 1500], x=x, pos=pos, batch=batch).to(DEV)
+    try:
+        saved = (ops.CONV_MODE, ops.DECODE_MODE)
+        ops.CONV_MODE, ops.DECODE_MODE = ops.CONV_FP32, "fp32"
+        want = PR.predict_batch(model, data, volume_size=24, auto_level=True)
+    finally:
+        ops.CONV_MODE, ops.DECODE_MODE = saved
+    orig, calls = ops.implicit_decode_split, {"n": 0}
+
+    def poisoned(xin, pack, out=None, xscale=None):
+        r = orig(xin, pack, out=out, xscale=xscale)
+        calls["n"] += 1
+        if calls["n"] == 1:
+            r[0] = float("nan")
+        return r
+    monkeypatch.setattr(ops, "implicit_decode_split", poisoned)
+    before = PR._FALLBACKS["count"]
+    with pytest.warns(UserWarning):
+        PR._FALLBACKS["count"] = 0
+        got = PR.predict_batch(model, data, volume_size=24, auto_level=True)
+    assert PR._FALLBACKS["count"] == 1
+    PR._FALLBACKS["count"] += before
+    for a, b in zip(got, want):
+        assert torch.equal(a["wnf_volume"], b["wnf_volume"]) and torch.equal(a["faces"], b["faces"])
+
+
 # ------------------------------------------------------------------------------------------------ isosurface
 def _gpu_mc_raw(vol, level):
     v = torch.from_numpy(np.ascontiguousarray(vol, np.float32)).to(DEV)
@@ -828,3 +905,52 @@ def test_chamfer_against_ckdtree():
     ref_f = np.linalg.norm(pred_sim - gt_sim[fi], axis=1).mean()
     ref_b = np.linalg.norm(gt_sim - pred_sim[bi], axis=1).mean()
     assert abs(float(h["hybrid_chamfer_forward"]) - ref_f) < 1e-6 and abs(float(h["hybrid_chamfer_backward"]) - ref_b) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ fused set abstraction
+@pytest.mark.parametrize("level", ["sa1", "sa2"])
+@pytest.mark.parametrize("self_loops", [True, False])
+def test_sa_fused_against_unfused_chain(level, self_loops):
+    """gn_sa_fused (gather -> edge MLP on the matrix cores -> BatchNorm -> max in one kernel) against the unfused chain
+    gn_sa_gather -> gn_linear x3 -> gn_segment_max on the same fps / ball-query tables: same exact-fp32 products, another summation
+    order -> 1e-5 relative; ragged batch, empty balls, balls beyond the 64-neighbour cap, centres past the last full group."""
+    from garmentnets_amd.components import pointnet2 as PN
+    from garmentnets_amd.components.mlp import MLP
+    sizes = [2500, 37, 1300, 1]
+    x0, pos, batch = _ragged_cloud(sizes, 77)
+    g = torch.Generator().manual_seed(3)
+    if level == "sa1":
+        cin, dims, ratio, rad = 3, [6, 64, 64, 128], 0.5, 0.05
+        x = x0
+    else:
+        cin, dims, ratio, rad = 128, [131, 128, 128, 256], 0.25, 0.1
+        x = torch.randn(pos.shape[0], 128, generator=g)
+    mod = PN.SAModule(ratio, rad, MLP(dims, batch_norm=True))
+    sd = {k: S.synthetic_tensor("sa." + k, tuple(v.shape), 5) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).eval()
+    mod.conv.add_self_loops = self_loops
+    xin = ops.new_rows(x.shape[0], cin, DEV)
+    xin.copy_(x.to(DEV))
+    seg = Segments(sizes, DEV)
+    try:
+        saved, PN.FUSED_SA = PN.FUSED_SA, True
+        out_f, cpos_f, cseg = mod(xin, pos.to(DEV), seg)
+        PN.FUSED_SA = False
+        out_u, cpos_u, _ = mod(xin, pos.to(DEV), seg)
+    finally:
+        PN.FUSED_SA = saved
+    assert out_f.shape == out_u.shape == (cseg.total, dims[-1]) and torch.equal(cpos_f, cpos_u)
+    err = float((out_f - out_u).abs().max())
+    scale = float(out_u.abs().max())
+    print(f"{level} self_loops={self_loops}: fused vs unfused max err {err:.2e} (max |y| {scale:.2f}, {cseg.total} centres)")
+    assert err <= 1e-5 * max(1.0, scale)
+    assert torch.equal(out_f == 0, out_u == 0) or err <= 1e-6
+
+
+def test_sa_fused_runs_in_the_pipeline(golden_dir):
+    """the fused kernel is what pointnet2_forward launches for the shipped hyper-parameters (both SA levels)"""
+    hp = S.default_hparams(grid=16)
+    model = _model(hp, 0)
+    assert model.pointnet2_nocs.sa1_module._fused_pack() is not None and model.pointnet2_nocs.sa2_module._fused_pack() is not None
+    assert ops.sa_fused_supported(3, [64, 64, 128]) and ops.sa_fused_supported(128, [128, 128, 256]) and not ops.sa_fused_supported(5, [64, 64, 128])

@@ -59,3 +59,40 @@ def test_two_rank_gloo_metrics_gather():
 def test_single_process_passthrough():
     assert parallel.gather_metrics([4, 2.0]) == [[4.0, 2.0] + [0.0] * 6]
     assert parallel.aggregate_throughput([[4, 2.0]]) == (2.0, 2.0)
+
+
+def _shard_worker(rank, world, port, total, n, seed, q):
+    import zlib
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = parallel.init(backend="gloo")
+    shard, (lo, hi) = parallel.shard_batch(total, n, seed, r, w)
+    # what the data path consumes on this rank: per-garment checksums of its shard, exchanged through the metrics all-gather
+    sums = [float(zlib.crc32(shard.pos[i * n:(i + 1) * n].numpy().tobytes()) % 65521) for i in range(hi - lo)]
+    gathered = parallel.gather_metrics([hi - lo] + sums, device="cpu")
+    q.put((r, lo, hi, gathered, int(shard.batch.max()) if hi > lo else -1))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_global_batch_is_the_concatenation_of_the_shards():
+    """config[3] in miniature: a seeded global batch of 5 garments, sharded over 2 gloo ranks with shard_batch; the shards, in rank order,
+    are exactly the single-process global batch (garment by garment), with local batch ids restarting at 0 on every rank"""
+    import zlib
+    from garmentnets_amd import synthetic as S
+    world, total, n, seed = 2, 5, 64, 77
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, total, n, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, gpos, _ = S.synthetic_cloud(total, n, seed=seed)
+    want = [float(zlib.crc32(gpos[i * n:(i + 1) * n].numpy().tobytes()) % 65521) for i in range(total)]
+    (r0, lo0, hi0, g0, m0), (r1, lo1, hi1, g1, m1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 5) and (m0, m1) == (2, 1)
+    assert g0 == g1 and len(g0) == 2                                   # every rank saw both ranks' records
+    got = g0[0][1:1 + int(g0[0][0])] + g0[1][1:1 + int(g0[1][0])]
+    assert got == want
