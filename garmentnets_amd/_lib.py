@@ -31,11 +31,12 @@ PROTOTYPES = {
     "gn_nocs_head": [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_features": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
     "gn_grid_scatter_workspace_bytes": [_i64, _i32, _i32],
-    "gn_grid_scatter": [_vp, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
+    "gn_grid_scatter": [_vp, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _sz, _i32, _vp],
     "gn_channel_stats": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "gn_groupnorm_affine": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_conv3d_gcr": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
-    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gn_grid_tile_flags": [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_stats": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_trilinear_sample": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i32, _vp],

@@ -4,6 +4,8 @@ Twin of the inlined steps of /root/reference/predict.py:160-181 (== common/march
 error contract of skimage.measure.marching_cubes(method='lewiner'): ValueError when the level is outside
 [min, max] (caught by predict.py:188), RuntimeError when no surface is found.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -96,6 +98,17 @@ def clear_iso_graphs():
     _ISO_GRAPHS.clear()
 
 
+_ISO_STREAMS = {}
+
+
+def _iso_streams(device, n):
+    pool = _ISO_STREAMS.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+ISO_STREAMS = int(os.environ.get("GARMENTNETS_ISO_STREAMS", "4"))     # concurrent slot-graph replays of wnf_batch_to_meshes_gpu (1 = in stream)
 USE_ISO_GRAPHS = True      # wnf_batch_to_meshes_gpu replays a captured graph per garment slot (False: plain launches)
 
 
@@ -113,6 +126,16 @@ def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_
     cap_v = max(4096, int(6 * Q ** 2))
     cap_f = 2 * cap_v + 64
     vols, ggms, mcs, recs = [], [], [], []
+    dev = wnf_all.device
+    main = torch.cuda.current_stream(dev)
+    # the garments are independent and one 128^3 volume does not fill 256 CUs (GGM / classify / scan / emit are small grids with
+    # dependent launches in between): the slot graphs are replayed round-robin on a few side streams, forked from and joined to the
+    # caller's stream
+    lanes = _iso_streams(dev, min(ISO_STREAMS, B)) if (USE_ISO_GRAPHS and ISO_STREAMS > 1 and B > 1 and not torch.cuda.is_current_stream_capturing()) else []
+    ready = None
+    if lanes:
+        ready = torch.cuda.Event()
+        ready.record(main)
     for b in range(B):
         vol = wnf_all[b].float().contiguous()
         vols.append(vol)
@@ -122,7 +145,13 @@ def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_
                 if len(_ISO_GRAPHS) >= 256:
                     _ISO_GRAPHS.clear()
                 _ISO_GRAPHS[key] = _IsoGraph(Q, level, float(sigma), cap_v, cap_f, vol.device)
-            ggm, mc, rec = _ISO_GRAPHS[key](vol)
+            if lanes:
+                st = lanes[b % len(lanes)]
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    ggm, mc, rec = _ISO_GRAPHS[key](vol)
+            else:
+                ggm, mc, rec = _ISO_GRAPHS[key](vol)
         else:
             ggm = ops.ggm3d(vol, sigma)
             mc = ops.mc33(vol, level, cap_v, cap_f)                # verts, faces, normals, values, counts (device)
@@ -130,6 +159,8 @@ def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_
         ggms.append(ggm)
         mcs.append(mc)
         recs.append(rec)
+    for st in lanes:
+        main.wait_stream(st)
     host = torch.stack(recs).cpu().numpy()                         # the one synchronisation
     out = []
     for b in range(B):

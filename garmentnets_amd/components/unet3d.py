@@ -38,9 +38,12 @@ class SingleConv(PackedModule, nn.Sequential):
         wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
         return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True):
+    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse_flat=None):
         """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
-        stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them."""
+        stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them.
+        sparse_flat: src0 is gn_grid_scatter's volume and this is the flat cell index of every scattered point -> occupancy-aware launch:
+        only the output tiles that can see an occupied cell go through the matrix cores, the rest are border-class constants taken from
+        a dense launch over a 3 x 3 x 3 all-zero volume with the same affine (bit-identical to the dense result, statistics included)."""
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None
@@ -56,7 +59,17 @@ class SingleConv(PackedModule, nn.Sequential):
             if key not in cache:
                 cache.clear()
                 cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
-            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], self.conv.out_channels, relu=True, with_stats=with_stats, act_inv=act_inv)
+            cout, sparse = self.conv.out_channels, {}
+            if (sparse_flat is not None and ops.SPARSE_FIRST_CONV and src1 is None and mode != ops.SPLIT_BF16X3 and cout % 128 == 0
+                    and src0.shape[-1] <= 384 and min(src0.shape[1:4]) >= 3):
+                B = src0.shape[0]
+                flags = ops.grid_tile_flags(sparse_flat, B, src0.shape[1:4])
+                zeros = torch.zeros((B, 3, 3, 3, src0.shape[-1]), dtype=torch.float32, device=src0.device)
+                every = torch.ones((B, 1), dtype=torch.uint8, device=src0.device)
+                dummy = torch.zeros((B, 27, cout), dtype=torch.float32, device=src0.device)
+                kconst = ops.conv3d_gcr_split(zeros, None, a, d, cache[key], cout, relu=True, act_inv=act_inv, tile_active=every, kconst=dummy)
+                sparse = dict(tile_active=flags, kconst=kconst.reshape(B, 27, cout))
+            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sparse)
             return r if with_stats else (r, None)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
         if with_stats:
@@ -76,8 +89,8 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
-    def run(self, src0, src1=None, stats0=None, stats1=None):
-        y, st = self.SingleConv1.run(src0, src1, stats0, stats1)
+    def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None):
+        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse_flat=sparse_flat)
         return self.SingleConv2.run(y, None, st)
 
 
@@ -87,14 +100,15 @@ class Encoder(nn.Module):
         self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=True, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, x, stats=None):
+    def run(self, x, stats=None, sparse_flat=None):
         if self.pooling is not None:
+            sparse_flat = None
             c = x.shape[-1]
             if c <= 256 and 256 % (c // 4) == 0:
                 x, stats = ops.maxpool3d_2(x, with_stats=True)
             else:
                 x, stats = ops.maxpool3d_2(x), None
-        return self.basic_module.run(x, None, stats)
+        return self.basic_module.run(x, None, stats, sparse_flat=sparse_flat)
 
 
 class Decoder(nn.Module):
@@ -136,13 +150,13 @@ class Abstract3DUNet(nn.Module):
         self.final_conv = FinalConv1x1(f_maps[0], out_channels, 1)
         self.final_activation = None
 
-    def run(self, x, stats=None, pre_final=False, return_stats=False):
+    def run(self, x, stats=None, pre_final=False, return_stats=False, sparse_flat=None):
         """channel-last in, channel-last out (pre_final: stop before the final 1x1x1 convolution -- it is linear, so the decoders can
         fold it into their first layer and sample the f_maps[0]-channel volume instead: networks/conv_implicit_wnf.py UNetResult).  Every kernel that produces a tensor also emits the per-channel statistics the
         next GroupNorm needs (conv / max-pool epilogues), so no activation is re-read for normalisation."""
         feats = []
-        for enc in self.encoders:
-            x, stats = enc.run(x, stats)
+        for i, enc in enumerate(self.encoders):
+            x, stats = enc.run(x, stats, sparse_flat=sparse_flat if i == 0 else None)
             feats.insert(0, (x, stats))
         for dec, (skip, skip_stats) in zip(self.decoders, feats[1:]):
             x, stats = dec.run(skip, x, skip_stats, stats)

@@ -427,6 +427,9 @@ extern "C" int gn_knn_interpolate(const float *xs, int ldx, const float *ps, con
         case 2: KNN_LAUNCH(2); break;
         case 3: KNN_LAUNCH(3); break;
         case 4: KNN_LAUNCH(4); break;
+        case 5: KNN_LAUNCH(5); break;
+        case 6: KNN_LAUNCH(6); break;
+        case 7: KNN_LAUNCH(7); break;
         default: KNN_LAUNCH(8); break;
     }
 #undef KNN_LAUNCH

@@ -46,6 +46,11 @@ struct SplitArgs {
     int tiles_y, tiles_x;
     const float *out_scale;   // [Cout] exact powers of two undoing the pack's per-output-channel weight scales (1 for the bf16 modes)
     const float *act_inv;     // NULL or [B]: exact power of two undoing the sample's activation scale (gn_groupnorm_affine)
+    // occupancy-aware launch (the first UNet layer, whose input is a scattered volume): tile_active[b][tile] == 0 -> the tile's halo
+    // holds no occupied cell, every output is one of 27 per-sample border-class constants kconst[b][class][Cout] (class =
+    // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
+    const unsigned char *tile_active;
+    const float *kconst;
 };
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -53,6 +58,7 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+// (GroupNorm affine in the halo stage: y = fma(x, a, d) -- one rounding, 4 VALU issue slots per 4 channels instead of 8)
 // four floats -> P bf16 planes (exact residual chain x = x1 + x2 [+ x3], xi = bf16_rn of the running residual), each plane
 // packed as 4 x bf16 = uint2.  v_cvt_pk_bf16_f32 rounds to nearest even like the host-side pack of the weights.
 template <int P, bool F16>
@@ -212,10 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 if (lo >= 0) {
                     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
                     if (goff0[PRE ? it : 0] >= 0) {                         // zero padding comes AFTER the affine
-                        v0 = __fadd_rn(__fmul_rn(raw[it].x, av.x), dv.x);
-                        v1 = __fadd_rn(__fmul_rn(raw[it].y, av.y), dv.y);
-                        v2 = __fadd_rn(__fmul_rn(raw[it].z, av.z), dv.z);
-                        v3 = __fadd_rn(__fmul_rn(raw[it].w, av.w), dv.w);
+                        v0 = __fmaf_rn(raw[it].x, av.x, dv.x);
+                        v1 = __fmaf_rn(raw[it].y, av.y, dv.y);
+                        v2 = __fmaf_rn(raw[it].z, av.z, dv.z);
+                        v3 = __fmaf_rn(raw[it].w, av.w, dv.w);
                     }
                     uint2 pl[P];
                     split4<P, F16>(v0, v1, v2, v3, pl);
@@ -265,10 +271,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                     const int hv = idx >> 2;
                     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
                     if (inb[it]) {                                          // zero padding comes AFTER the affine
-                        v0 = __fadd_rn(__fmul_rn(raw[it].x, av.x), dv.x);
-                        v1 = __fadd_rn(__fmul_rn(raw[it].y, av.y), dv.y);
-                        v2 = __fadd_rn(__fmul_rn(raw[it].z, av.z), dv.z);
-                        v3 = __fadd_rn(__fmul_rn(raw[it].w, av.w), dv.w);
+                        v0 = __fmaf_rn(raw[it].x, av.x, dv.x);
+                        v1 = __fmaf_rn(raw[it].y, av.y, dv.y);
+                        v2 = __fmaf_rn(raw[it].z, av.z, dv.z);
+                        v3 = __fmaf_rn(raw[it].w, av.w, dv.w);
                     }
                     uint2 pl[P];
                     split4<P, F16>(v0, v1, v2, v3, pl);
@@ -392,15 +398,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 // at taps 8-12, ordered by the per-tap barriers alone.  The matrix-core stream never stops for staging.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-template <int P, bool F16>
+// ZTWIN (the 32-wide layers, Cout % 64 != 0: 26 % of the step at 0.41 of the roofline in round 1): the same 8-wave machine, but the two
+// wave groups take two z-ADJACENT 4 x 8 x 8 tiles (one 8 x 8 x 8 block, ONE 10 x 10 x 10 halo: 1.95 staged voxels per output voxel
+// instead of 2.34) of the SAME 32 output channels and share every DMA'd B fragment.  What it buys over conv3d_split_kernel<1,...>:
+// the staging of slice s+1 rides inside the matrix-core stream of slice s (double-buffered halo) instead of stopping it.
+template <int P, bool F16, bool ZTWIN>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
     static_assert(P == 2, "the wide variant is sized for the two-plane modes");
-    constexpr int NT = 2;
-    using HL = HaloLayout<P>;
+    constexpr int NT = ZTWIN ? 1 : 2;
+    constexpr int TZ = ZTWIN ? 2 * SP_TZ : SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
+    constexpr int CW = ZTWIN ? 32 : 128;            // output channels per workgroup
+    using HL = HaloLayout<P, HZ>;
     constexpr int HALO_BYTES = HL::BYTES;
-    constexpr int BTAP = 2 * NT * P * 1024;         // both column groups
-    constexpr int DEPTH = 4, CH = 1;                // 8 one-KB pieces per step, one per wave
-    constexpr int NIT = (SP_HVOX * 4 + 511) / 512;  // 5 row loads per thread per slice
+    constexpr int NPIECE = (ZTWIN ? 1 : 2) * NT * P; // 1-KB B fragments per step: both column groups / the one shared column block
+    constexpr int BTAP = NPIECE * 1024;
+    constexpr int DEPTH = 4, CH = 1;                // one piece per wave per step (ZTWIN: the 2 pieces are fetched 4 times over, harmlessly)
+    constexpr int NIT = (HVOX * 4 + 511) / 512;     // 5 (8 for ZTWIN) row loads per thread per slice
     constexpr int AD_OFF = 2 * HALO_BYTES + DEPTH * BTAP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AD_OFF + 2 * 384 * 4];
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + 2 * HALO_BYTES;
@@ -410,18 +423,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     const int Cin = p.C0 + p.C1;
     const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
     const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
-    const int ncb = p.Cout / 128;
+    const int ncb = p.Cout / CW;
     int tile = (int)(logical / (unsigned)ncb);
     const int cb = (int)(logical % (unsigned)ncb);
-    const int tiles_z = (p.D + 3) / 4;
+    const int tiles_z = (p.D + TZ - 1) / TZ;
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
-    const int z0 = tz * SP_TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
-    const int n0 = cb * 128 + cg * 64;
+    const int z0 = tz * TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
+    const int n0 = ZTWIN ? cb * 32 : cb * 128 + cg * 64;
+    const int zl = ZTWIN ? zs + 4 * cg : zs;        // this wave's z-slice inside the tile
     const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
     const int nslices = Cin / SP_KS;
+    const bool inactive = p.tile_active && !p.tile_active[(int64_t)b * (tiles_z * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tiles_z + tz];
 
     f32x16s acc[2][NT], tot[2][NT];
 #pragma unroll
@@ -431,14 +446,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
+    if (!inactive) {                                // (workgroup-uniform: an inactive tile issues no DMA, no staging, no MFMA)
     for (int i = tid; i < Cin; i += 512) { adl[i] = p.a[(int64_t)b * Cin + i]; adl[384 + i] = p.d[(int64_t)b * Cin + i]; }
 
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
-    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + wave * 1024 + lane * 16;
+    const int piece = ZTWIN ? (wave & (NPIECE - 1)) : wave;
+    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + piece * 1024 + lane * 16;
     int jf = 0;
 #define SPW_ISSUE_B()                                                                                                          \
     do {                                                                                                                       \
-        gn_glds16(bg, lds_ring + (jf & (DEPTH - 1)) * BTAP + wave * 1024);                                                     \
+        gn_glds16(bg, lds_ring + (jf & (DEPTH - 1)) * BTAP + piece * 1024);                                                    \
         bg += bstep; ++jf;                                                                                                     \
     } while (0)
 #pragma unroll
@@ -458,10 +475,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * 512;
-            const int hv = (idx < SP_HVOX * 4 ? idx : SP_HVOX * 4 - 1) >> 2;
+            const int hv = (idx < HVOX * 4 ? idx : HVOX * 4 - 1) >> 2;
             const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool in = idx < SP_HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const bool in = idx < HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             int64_t off = (int64_t)b * (from1 ? (int64_t)D1 * H1 * W1 : (int64_t)p.D * p.H * p.W) * Cs;   // a valid address when outside
             if (in) {
                 if (from1) off = ((((int64_t)b * D1 + (gz >> 1)) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * Cs + cs + c4;
@@ -474,16 +491,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     auto convert_row = [&](int it, int sl, int buf) {
         const int idx = tid + it * 512;
         asm volatile("" : "+v"(raw[it]));           // the loads above are invisible to hipcc's waitcnt pass: pin the first use here
-        if (idx < SP_HVOX * 4) {
+        if (idx < HVOX * 4) {
             const int hv = idx >> 2;
             const float4 av = *reinterpret_cast<const float4 *>(adl + sl * SP_KS + c4);
             const float4 dv = *reinterpret_cast<const float4 *>(adl + 384 + sl * SP_KS + c4);
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
             if (inb & (1u << it)) {                  // zero padding comes AFTER the affine
-                v0 = __fadd_rn(__fmul_rn(raw[it].x, av.x), dv.x);
-                v1 = __fadd_rn(__fmul_rn(raw[it].y, av.y), dv.y);
-                v2 = __fadd_rn(__fmul_rn(raw[it].z, av.z), dv.z);
-                v3 = __fadd_rn(__fmul_rn(raw[it].w, av.w), dv.w);
+                v0 = __fmaf_rn(raw[it].x, av.x, dv.x);
+                v1 = __fmaf_rn(raw[it].y, av.y, dv.y);
+                v2 = __fmaf_rn(raw[it].z, av.z, dv.z);
+                v3 = __fmaf_rn(raw[it].w, av.w, dv.w);
             }
             uint2 pl[P];
             split4<P, F16>(v0, v1, v2, v3, pl);
@@ -500,9 +517,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     for (int it = 0; it < NIT; ++it) convert_row(it, 0, 0);
     __syncthreads();
 
-    const int abase = HL::at(zs, r >> 3, r & 7) + 16 * h;
+    const int abase = HL::at(zl, r >> 3, r & 7) + 16 * h;
     constexpr int AF1 = 4 * HL::ROWP;
-    const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (cg * NT * P) * 1024 + lane * 16;
+    const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (ZTWIN ? 0 : cg * NT * P) * 1024 + lane * 16;
     int jcur = 0;
     uint4 bf[NT][P];                                // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
 #pragma unroll
@@ -530,11 +547,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             //  waits for each of them right before the MFMA that consumes it; a blanket lgkmcnt(0) here would expose their LDS
             //  latency at every barrier.  The slot the DMA below overwrites, step j-1's, was consumed by MFMAs every wave has issued.
             //  Tap 26 drains the LDS queue once per slice so that the staged rows of the next slice are visible after its barriers.)
-            if (tap == 26) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
-            else if (tap >= 1 && tap <= 2) GN_WAIT_VM_ONLY((DEPTH - 3) * CH + NIT);
-            else GN_WAIT_VM_ONLY((DEPTH - 3) * CH);
-            __builtin_amdgcn_s_barrier();
-            SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
+            if (!ZTWIN) {
+                if (tap == 26) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
+                else if (tap >= 1 && tap <= 2) GN_WAIT_VM_ONLY((DEPTH - 3) * CH + NIT);
+                else GN_WAIT_VM_ONLY((DEPTH - 3) * CH);
+                __builtin_amdgcn_s_barrier();
+                SPW_ISSUE_B();                      // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
+            } else if ((tap & 1) == 0) {
+                // ZTWIN: a wave has only 6 MFMAs per tap, so the hand-over (wait + barrier + DMA issue) is paid once per PAIR of taps
+                // (0,1) ... (24,25), (26): step j is in registers, steps j+1 and j+2 (issued one hand-over ago) must have landed --
+                // everything outstanding except the NIT row loads issued after the hand-over of tap 0 -- and the slots of steps
+                // j-1 and j are free for steps j+3 and j+4 (tap 26 is alone: one step)
+                if (tap == 26) GN_WAIT_VM_LGKM0(0);
+                else if (tap == 2) GN_WAIT_VM_ONLY(NIT);
+                else GN_WAIT_VM_ONLY(0);
+                __builtin_amdgcn_s_barrier();
+                SPW_ISSUE_B();
+                if (tap < 26) SPW_ISSUE_B();
+            }
             if (tap + 1 < 27) {
                 const int t1 = tap + 1;
                 const int toff = HL::at(t1 / 9, (t1 / 3) % 3, t1 % 3);
@@ -571,8 +601,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     }
 #undef SPW_ISSUE_B
     GN_WAIT_VM_LGKM0(0);
+    }
     __syncthreads();                                // pad-step DMAs landed; the epilogue reuses the halo as scratch
-    const int gz = z0 + zs;
+    const int gz = z0 + zl;
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
@@ -587,15 +618,33 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = __fmul_rn(tot[t][u][q], osc);
-                    if (p.relu) v = gn_relu(v);
+                    float v;
+                    if (inactive) {                  // the finished value (scale and ReLU applied) a dense launch gives a voxel of this border class
+                        const int cls = ((gz == 0 ? 0 : (gz == p.D - 1 ? 2 : 1)) * 3 + (gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1))) * 3 + (gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1));
+                        v = p.kconst[((int64_t)b * 27 + cls) * p.Cout + n];
+                    } else {
+                        v = __fmul_rn(tot[t][u][q], osc);
+                        if (p.relu) v = gn_relu(v);
+                    }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
                     ssq[u] = fmaf(v, v, ssq[u]);
                 }
             }
         }
-    if (p.osum) {
+    if (p.osum && ZTWIN) {
+        float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][wave][32]
+        const float s2 = ssum[0] + __shfl_xor(ssum[0], 32), q2 = ssq[0] + __shfl_xor(ssq[0], 32);
+        if (h == 0) { red[wave * 32 + r] = s2; red[256 + wave * 32 + r] = q2; }
+        __syncthreads();
+        if (tid < 32) {
+            double s8 = 0.0, q8 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s8 += (double)red[w * 32 + tid]; q8 += (double)red[256 + w * 32 + tid]; }
+            atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s8);
+            atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q8);
+        }
+    } else if (p.osum) {
         float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][cg][zs][64]
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -614,9 +663,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     }
 }
 
+// The z-twin variant is OFF by default: measured on MI355X (B=16, 128^3, the three 32-wide layers) it reaches 315 (one hand-over per
+// tap) / 323 (one per tap pair) TFLOP/s-equivalent against 331-344 for conv3d_split_kernel<1,...> with its synchronous staging and two
+// independent workgroups per CU.  A 32-wide layer does 3.3x the staging work per MFMA of a 128-wide one whatever the tiling (16 MFMA
+// k-steps per staged voxel-slice instead of 55): hiding the staging does not remove its issue slots.  GARMENTNETS_ZTWIN=1 selects it
+// for A/B runs.
+static bool gn_ztwin_enabled() {
+    static const bool on = [] { const char *e = getenv("GARMENTNETS_ZTWIN"); return e && e[0] == '1'; }();
+    return on;
+}
+
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
-                                   int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, void *stream) {
+                                   int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
+                                   const float *kconst, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -632,6 +692,7 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
+    p.tile_active = tile_active; p.kconst = kconst;
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
@@ -647,11 +708,20 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
         gn_note_kernel(wide ? "conv3d_split_kernel<2, " #P_ ", " #F16_ ", 1>" : "conv3d_split_kernel<1, " #P_ ", " #F16_ ", 1>"); \
     } while (0)
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
-    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && (int64_t)tiles * (Cout / 128) * B >= 512;
+    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && ((int64_t)tiles * (Cout / 128) * B >= 512 || tile_active);
+    GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
+    GN_REQUIRE(!tile_active || (wide128 && D >= 3 && H >= 3 && W >= 3), "gn_conv3d_gcr_split: the occupancy-aware launch needs the 128-wide variant (two-plane mode, Cout %% 128 == 0, Cin <= 384) and dims >= 3");
+    // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
+    const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
+    const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
     if (wide128) {
-        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true>" : "conv3d_split_wide_kernel<2, false>");
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false>" : "conv3d_split_wide_kernel<2, false, false>");
+    } else if (ztwin) {
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, true>), dim3(tiles8 * (Cout / 32), B), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, true>), dim3(tiles8 * (Cout / 32), B), dim3(512), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, true>" : "conv3d_split_wide_kernel<2, false, true>");
     } else
     if (mode == GN_SPLIT_BF16X3) SP_LAUNCH(3, false);
     else if (mode == GN_SPLIT_BF16X2) SP_LAUNCH(2, false);

@@ -40,7 +40,10 @@ class Group:
         return g
 
     def put_attrs(self, attrs):
-        _write_json(os.path.join(self.path, ".zattrs"), attrs)
+        """merge `attrs` into the group's .zattrs"""
+        merged = dict(self.attrs)
+        merged.update(attrs)
+        _write_json(os.path.join(self.path, ".zattrs"), merged)
 
     def array(self, name, data, chunks=None, compressor=None, overwrite=True):
         """C-order Zarr v2 array; chunks=None -> one chunk (chunks == data.shape: what the reference's prediction.zarr uses), else a
@@ -128,8 +131,18 @@ def _read_array(path):
     return out
 
 
+CODEC_NOTE = ("chunks are stored with Zarr v2's stdlib codec {'id': 'zlib'} (or uncompressed) instead of the reference's "
+              "Blosc(cname='zstd', clevel=6, shuffle=BITSHUFFLE) (predict.py:77): numcodecs is not available offline; group / array / dtype / "
+              "shape layout is the reference's")
+
+
 def open_group(path, create=True):
-    return Group(path, create=create)
+    """root group of a store; a store created here records the one deviation from the reference's on-disk format in its .zattrs"""
+    fresh = create and not os.path.exists(os.path.join(path, ".zgroup"))
+    g = Group(path, create=create)
+    if fresh:
+        g.put_attrs({"codec_note": CODEC_NOTE})
+    return g
 
 
 def write_sample(samples_group, key, mesh, point_cloud, misc, attrs=None, compressor=("zlib", 1)):

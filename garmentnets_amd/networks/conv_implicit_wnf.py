@@ -32,6 +32,31 @@ class VolumeFeatureAggregator(nn.Module):
         self.include_point_feature = include_point_feature
         self.include_confidence_feature = include_confidence_feature
 
+    def prefetch_zero(self, B, device):
+        """zero-fill the (B, G, G, G, C) volume of the NEXT forward() on a side stream, now: the fill (17 GB at batch 16, 128^3: 3 ms of
+        pure HBM writes) then runs next to PointNet++'s serial farthest-point sampling (16 workgroups on 256 CUs) instead of after it"""
+        if not PREFETCH_ZERO or not torch.cuda.is_available():
+            return
+        C = self.local_nn[-1][0].out_features if self.local_nn is not None else None
+        if C is None:
+            return
+        dev = torch.device(device)
+        pre = self.__dict__.get("_prezero")
+        if pre is not None and pre[0] == B and pre[1].device == dev:
+            return                                   # the previous prefetch was never consumed (pointnet2_forward alone in a loop): still zero
+        if B * int(torch.tensor(self.grid_shape).prod()) * C * 4 < (64 << 20):
+            return                                   # small volumes: the in-stream memset costs microseconds
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_side")
+        if side is None or side.device != dev:
+            side = self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                       # the blocks the allocator hands out were last used on the main stream
+        with torch.cuda.stream(side):
+            vol, cnt = ops.zeroed_volume(B, self.grid_shape, C, dev)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.__dict__["_prezero"] = (B, vol, cnt, ev)
+
     def forward(self, nocs_data):
         B = nocs_data.num_graphs
         conf = nocs_data.pred_confidence
@@ -40,9 +65,15 @@ class VolumeFeatureAggregator(nn.Module):
                                         self.include_point_feature, self.include_confidence_feature)
         if self.local_nn is not None:
             feats = self.local_nn(feats)
-        vol, stats = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method, with_stats=True)   # [B][G][G][G][C]
+        pre = self.__dict__.pop("_prezero", None)
+        prezeroed = None
+        if pre is not None and pre[0] == B and pre[1].shape[-1] == feats.shape[1] and pre[1].device == feats.device:
+            torch.cuda.current_stream(feats.device).wait_event(pre[3])
+            prezeroed = (pre[1], pre[2])
+        vol, stats = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method, with_stats=True, prezeroed=prezeroed)   # [B][G][G][G][C]
         out = vol.permute(0, 4, 1, 2, 3)
         out._gn_stats = stats      # GroupNorm statistics of the (mostly empty) volume, from its occupied cells only
+        out._gn_flat = flat        # the occupied cells: the first UNet convolution only visits the tiles that can see one
         return out
 
 
@@ -62,11 +93,12 @@ class ImplicitWNFDecoder(PackedModule):
 
     The MLP runs as ONE kernel (gn_implicit_decode: hidden activations stay in LDS) when it has the shipped shape
     [C0, N1, N2, out<=4] with N1, N2 multiples of 256; otherwise gn_linear per layer.  Sampling is a separate
-    high-occupancy kernel feeding it through a chunk buffer small enough to stay in the 256 MB Infinity Cache
+    high-occupancy kernel feeding it through a chunk buffer (2^20 rows x 32 channels = 134 MB: half a 128^3 lattice per launch pair; 2^18
+    rows measured 1 ms slower per 16-garment step, the whole lattice no faster) small enough to stay in the 256 MB Infinity Cache
     (measured on MI355X, 128^3 lattice: sample 1.96 ms + MLP 4.47 ms vs 9.55 ms for sampling inside the MLP kernel,
     where the latency-bound gathers cannot overlap the matrix-core phases of the only two resident workgroups)."""
 
-    ROWS_PER_CHUNK = 1 << 18
+    ROWS_PER_CHUNK = int(os.environ.get("GARMENTNETS_DECODE_CHUNK", 1 << 20))
     fused = True
 
     def __init__(self, nn_channels=(128, 512, 512, 1), batch_norm=True):
@@ -212,6 +244,9 @@ class ImplicitWNFDecoder(PackedModule):
         return out
 
 
+# zero-fill of the scattered volume overlapped with PointNet++ (VolumeFeatureAggregator.prefetch_zero)
+PREFETCH_ZERO = os.environ.get("GARMENTNETS_PREFETCH_ZERO", "1") != "0"
+
 # the decoders fold the UNet's final 1x1x1 convolution into their first layer (ImplicitWNFDecoder.folded_pack); False restores the
 # reference's literal order of operations (materialise the 128-channel volume, then sample it)
 FOLD_FINAL_CONV = os.environ.get("GARMENTNETS_FOLD_FINAL_CONV", "1") != "0"
@@ -333,6 +368,9 @@ class ConvImplicitWNFPipeline(nn.Module):
 
     # -- stages ----------------------------------------------------------------------------------------------
     def pointnet2_forward(self, data):
+        sizes = data._sizes if hasattr(data, "_sizes") else None
+        if sizes is not None and data.pos.is_cuda:   # (no host sizes: the batch size would cost a device synchronisation here)
+            self.volume_agg.prefetch_zero(len(sizes), data.pos.device)
         result = self.pointnet2_nocs(data)
         bins = self.pointnet2_nocs.nocs_bins
         _, confidence, pred_nocs = ops.nocs_head(result["per_point_logits"], bins)
@@ -343,7 +381,8 @@ class ConvImplicitWNFPipeline(nn.Module):
     def unet3d_forward(self, pointnet2_result):
         in_feature_volume = self.volume_agg(pointnet2_result["nocs_data"])
         net = self.unet_3d.abstract_3d_unet
-        pre, st = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True, return_stats=True)
+        pre, st = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True, return_stats=True,
+                          sparse_flat=getattr(in_feature_volume, "_gn_flat", None))
         return UNetResult(pre, net.final_conv, st)   # ['out_feature_volume'] materialises the reference's tensor on demand
 
     def volume_decoder_forward(self, unet3d_result, query_points):

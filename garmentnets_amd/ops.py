@@ -223,17 +223,30 @@ def grid_features(feat, nocs, sim_pos, conf, batch, lower, upper, grid_shape, in
     return out, flat
 
 
-def grid_scatter(src, flat_idx, B, grid_shape, reduce, with_stats=False):
-    """-> channel-last volume [B][G0][G1][G2][C] (and its per-channel statistics, from the occupied cells only)"""
+def zeroed_volume(B, grid_shape, C, device):
+    """(vol, count workspace) of grid_scatter, zero-filled on torch's CURRENT stream (callers put it on a side stream)"""
+    vol = torch.zeros((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=device)
+    cnt = torch.zeros(B * int(np.prod(grid_shape)), dtype=_i32, device=device)
+    return vol, cnt
+
+
+def grid_scatter(src, flat_idx, B, grid_shape, reduce, with_stats=False, prezeroed=None):
+    """-> channel-last volume [B][G0][G1][G2][C] (and its per-channel statistics, from the occupied cells only).
+    prezeroed: (vol, cnt) from zeroed_volume that the caller has already ordered before this call"""
     N, C = src.shape
     cps = int(np.prod(grid_shape))
     cells = B * cps
-    vol = torch.empty((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=src.device)
-    cnt = torch.empty(cells, dtype=_i32, device=src.device)
+    if prezeroed is not None:
+        vol, cnt = prezeroed
+        assert vol.shape == (B,) + tuple(grid_shape) + (C,) and cnt.numel() == cells
+    else:
+        vol = torch.empty((B,) + tuple(grid_shape) + (C,), dtype=torch.float32, device=src.device)
+        cnt = torch.empty(cells, dtype=_i32, device=src.device)
     code = {"max": 0, "mean": 1}[reduce]
     nbytes = _lib.load().gn_grid_scatter_workspace_bytes(N, C, code)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=src.device) if nbytes else None
-    _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _p(ws), nbytes, _stream())
+    _lib.call("gn_grid_scatter", _p(src), rows_view(src)[1], _p(flat_idx), N, C, cells, code, _p(vol), _p(cnt), _p(ws), nbytes,
+              0 if prezeroed is None else 1, _stream())
     if not with_stats:
         return vol
     s, q = _stats_buffers(B, C, src.device, True)
@@ -338,13 +351,26 @@ def pack_conv_weight_split(w, mode):
     return SplitPack(pk.contiguous().view(torch.int16), mode, (1.0 / scale).contiguous().to(w.device))
 
 
-def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None):
+def grid_tile_flags(flat_idx, B, grid_shape):
+    """uint8 [B][tiles]: the 4 x 8 x 8 output tiles of a 3x3x3 conv over the scattered volume that can see an occupied cell"""
+    g0, g1, g2 = [int(v) for v in grid_shape]
+    tiles = -(-g0 // 4) * -(-g1 // 8) * -(-g2 // 8)
+    flags = torch.empty((B, tiles), dtype=torch.uint8, device=flat_idx.device)
+    _lib.call("gn_grid_tile_flags", _p(_chk(flat_idx, _i32, "flat_idx")), flat_idx.numel(), B, g0, g1, g2, _p(flags), _stream())
+    return flags
+
+
+# occupancy-aware first UNet convolution (exact: bit-identical to the dense launch); "0" = always dense
+SPARSE_FIRST_CONV = os.environ.get("GARMENTNETS_SPARSE_CONV", "1") != "0"
+
+
+def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
     _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
-              1 if relu else 0, _p(out), _p(s), _p(q), _stream())
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

@@ -125,10 +125,15 @@ int gn_grid_features(const float *feat, int ldf, int Cf, const float *nocs, cons
  * networks/conv_implicit_wnf.py:92-94.  reduce: 0 = max, 1 = mean.  vol [cells][C] must be zeroed by this
  * call (it does the memset); count_ws: [cells] int32 workspace.  Empty cells stay 0.  Both reductions are
  * deterministic (run-to-run bit-identical): max by construction, mean through order-independent fp64 partial sums
- * kept in `ws` (gn_grid_scatter_workspace_bytes(N, C, reduce) bytes; 0 / NULL for max). */
+ * kept in `ws` (gn_grid_scatter_workspace_bytes(N, C, reduce) bytes; 0 / NULL for max).  vol_is_zeroed != 0: the caller has already
+ * zero-filled vol and count_ws (e.g. on a side stream, overlapped with the serial FPS kernels) and the memsets are skipped. */
 size_t gn_grid_scatter_workspace_bytes(int64_t N, int C, int reduce);
 int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t N, int C, int64_t cells, int reduce,
-                    float *vol, int32_t *count_ws, void *ws, size_t ws_bytes, void *stream);
+                    float *vol, int32_t *count_ws, void *ws, size_t ws_bytes, int vol_is_zeroed, void *stream);
+
+/* Output tiles (4 x 8 x 8 voxels, the tiling of gn_conv3d_gcr_split) of a 3x3x3 convolution over the scattered volume that can see an
+ * occupied cell: flags [B][tiles_y * tiles_x * tiles_z] bytes (zeroed inside), index (ty * tiles_x + tx) * tiles_z + tz. */
+int gn_grid_tile_flags(const int32_t *flat_idx, int64_t N, int B, int G0, int G1, int G2, unsigned char *flags, void *stream);
 
 /* Per-(sample, channel) sum / sum of squares of a scattered volume computed from its OCCUPIED cells only (all other
  * cells are zero): the GroupNorm statistics of the first UNet layer without reading the (mostly empty) volume.
@@ -181,9 +186,16 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
 #define GN_SPLIT_BF16X2 2
 #define GN_SPLIT_BF16X3 3
 #define GN_SPLIT_F16X2 4
+/* Occupancy-aware launch (the layer whose input is gn_grid_scatter's volume, > 99 % empty for 6000 points in 128^3 cells):
+ * tile_active (NULL, or [B][tiles] bytes from gn_grid_tile_flags) marks the 4 x 8 x 8 output tiles whose halo holds an occupied cell;
+ * every other tile's outputs are border-class constants kconst [B][27][Cout] (class (cz*3 + cy)*3 + cx, c = 0 first voxel of the
+ * axis / 1 interior / 2 last voxel; the FINISHED values a dense launch produces there -- garmentnets_amd takes them from a dense
+ * launch over a small all-zero volume with the same affine) and are stored without touching the matrix cores.  Bit-identical to
+ * the dense launch, statistics included.  128-wide variant only (two-plane modes, Cout % 128 == 0, C0 + C1 <= 384). */
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                         const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H, int W,
-                        int Cout, int relu, float *out, double *out_sum, double *out_sumsq, void *stream);
+                        int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
+                        const float *kconst, void *stream);
 
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */

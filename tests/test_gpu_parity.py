@@ -954,3 +954,40 @@ def test_sa_fused_runs_in_the_pipeline(golden_dir):
     model = _model(hp, 0)
     assert model.pointnet2_nocs.sa1_module._fused_pack() is not None and model.pointnet2_nocs.sa2_module._fused_pack() is not None
     assert ops.sa_fused_supported(3, [64, 64, 128]) and ops.sa_fused_supported(128, [128, 128, 256]) and not ops.sa_fused_supported(5, [64, 64, 128])
+
+
+# ------------------------------------------------------------------------------------------------ occupancy-aware first convolution
+@pytest.mark.parametrize("G,mode", [(32, 4), (36, 4), (20, 2)])
+def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
+    """the first UNet convolution on a scattered volume: only the tiles that can see an occupied cell go through the matrix cores, the
+    rest are border-class constants (csrc/unet_split.hip tile_active / kconst).  The output must equal the dense launch bit for bit (the
+    epilogue statistics up to the order of their fp64 atomics): occupied cells in corners / on faces / in the interior, a garment without any point, a grid that is not a
+    multiple of the tile."""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(G)
+    B, C, Cout = 3, 128, 128
+    cells = [torch.tensor([[0, 0, 0], [G - 1, G - 1, G - 1], [0, G - 1, 5], [G // 2, G // 2, G // 2], [G // 2, G // 2, G // 2 + 1], [3, 8, 9], [4, 7, 8]]),
+             torch.zeros((0, 3), dtype=torch.int64),
+             torch.randint(0, G, (200, 3), generator=g)]
+    flat = torch.cat([(((b * G + c[:, 0]) * G + c[:, 1]) * G + c[:, 2]) for b, c in enumerate(cells)]).to(torch.int32)
+    feats = torch.randn(flat.numel(), C, generator=g)
+    vol, stats = ops.grid_scatter(feats.to(DEV), flat.to(DEV), B, (G, G, G), "max", with_stats=True)
+    conv = SingleConv(C, Cout)
+    sd = {k: S.synthetic_tensor("c." + k, tuple(v.shape), 1) for k, v in conv.state_dict().items()}
+    conv.load_state_dict(sd)
+    conv = conv.to(DEV)
+    try:
+        saved_mode, saved_sp = ops.CONV_MODE, ops.SPARSE_FIRST_CONV
+        ops.CONV_MODE, ops.SPARSE_FIRST_CONV = mode, True
+        y_s, (s_s, q_s, V) = conv.run(vol, None, stats, None, sparse_flat=flat.to(DEV))
+        flags = ops.grid_tile_flags(flat.to(DEV), B, (G, G, G))
+        y_d, (s_d, q_d, _) = conv.run(vol, None, stats, None)
+    finally:
+        ops.CONV_MODE, ops.SPARSE_FIRST_CONV = saved_mode, saved_sp
+    active = flags.sum(dim=1).tolist()
+    print(f"G={G} mode={mode}: active tiles per garment {active} of {flags.shape[1]}")
+    assert active[1] == 0 and 0 < active[0] < flags.shape[1]
+    assert torch.equal(y_s, y_d)
+    # the statistics are fp64 atomic sums of identical per-tile fp32 partials: equal up to the order of the fp64 additions (1 ulp)
+    assert float(((s_s - s_d).abs() / s_d.abs().clamp_min(1e-30)).max()) <= 1e-13 and float(((q_s - q_d).abs() / q_d.abs().clamp_min(1e-30)).max()) <= 1e-13
+    assert bool(torch.isfinite(y_s).all()) and float(y_s.abs().max()) > 0

@@ -23,13 +23,23 @@ def load(path):
 # default 2.0; the split-operand kernels read their halos exactly like the fp32 kernels (64-byte pieces at a channel stride)
 FETCH_FACTOR = {"conv3d_gcr_kernel<2>": 1.26, "conv3d_gcr_kernel<1>": 1.42,
                 "conv3d_split_wide_kernel<2, true>": 1.26, "conv3d_split_wide_kernel<2, false>": 1.26,
+                "conv3d_split_wide_kernel<2, true, false>": 1.26, "conv3d_split_wide_kernel<2, false, false>": 1.26,
+                "conv3d_split_wide_kernel<2, true, true>": 1.42, "conv3d_split_wide_kernel<2, false, true>": 1.42,
                 "conv3d_split_kernel<1, 2, true, 1>": 1.42, "conv3d_split_kernel<2, 2, true, 1>": 1.42,
                 "conv3d_split_kernel<1, 2, false, 1>": 1.42, "conv3d_split_kernel<2, 2, false, 1>": 1.42,
                 "conv3d_split_kernel<1, 3, false, 1>": 1.42, "conv3d_split_kernel<2, 3, false, 1>": 1.26}
 
 
-fetch = load(sys.argv[1] + "/pmc_counter_collection.csv")
-write = load(sys.argv[2] + "/pmc_counter_collection.csv")
+import glob
+
+
+def find(d):
+    c = glob.glob(d + "/*counter_collection.csv")
+    return c[0] if c else d + "/pmc_counter_collection.csv"
+
+
+fetch = load(find(sys.argv[1]))
+write = load(find(sys.argv[2]))
 out = {"units": "bytes per launch (average over the run)", "fetch_correction": "2.0 unless listed per kernel (calibrated)", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     if fetch[k][1] < 1024:
