@@ -7,11 +7,15 @@
 // products, fp32 accumulation, 16x the k-throughput of v_mfma_f32_32x32x2_f32):
 //   P = 3 : 6 products x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1   -> dropped terms <= 2^-24 relative: fp32-class products
 //   P = 2 : 3 products x1w1 + x1w2 + x2w1                       -> 2^-16 relative per product
-// A third mode uses fp16 planes (11-bit significands): x = x1 + x2 leaves <= 2^-22 |x| and the same 3 products drop only
-// x2w2 <= 2^-22 -- half the matrix-core work of bf16 x 3 at an error far below that of the fp32 accumulation of a 27*Cin-term
-// dot product.  fp16's narrow exponent is handled by a power-of-two scale of the weight tensor (max |w| in [1,2), undone
-// exactly in the epilogue); activations are GroupNorm outputs (|x| <= sqrt(group size)*|gamma|+|beta|), values beyond
-// +-65504 would turn into inf and show up as inf/NaN in the output, never as a silently wrong finite number.
+// A third mode uses fp16 planes (11-bit significands): x = x1 + x2 leaves <= 2^-22 |x| WHEN BOTH PLANES ARE NORMAL, and the same 3
+// products drop only x2w2 -- half the matrix-core work of bf16 x 3 at an error far below that of the fp32 accumulation of a 27*Cin-term
+// dot product.  fp16's narrow exponent is handled by exact power-of-two scales: one per OUTPUT CHANNEL for the weights
+// (row maximum in [1, 2); a weight below 2^-3 of its row's largest has a subnormal second plane: residual 2^-25 of the row maximum) and
+// one per SAMPLE for the activations, chosen on the device from the GroupNorm statistics (largest per-channel rms of the normalised
+// activations in [1, 2): gn_groupnorm_affine's act_inv_scale) -- a channel's values are bounded by rms * sqrt(V), so fp16 cannot
+// overflow for any checkpoint, and values down to 1/8 of the sample's typical magnitude keep a normal second plane (below: residual
+// 2^-25 of that magnitude, absolute).  Both scales are undone exactly in the epilogue.  Without the sample scale (act_inv == NULL, the
+// raw kernel) a GroupNorm output beyond +-65504 turns into inf and shows up as inf/NaN in the output, never as a wrong finite number.
 // One bf16 MFMA consumes the 16-channel slice of a tap at once: lane (h = lane>>5, r = lane&31) supplies channels 8h..8h+7
 // of voxel r (A) / of output channel r (B) -- the same fragment the fp32 kernel reads, so the LDS layout is the fp32 one
 // with P bf16 planes per voxel.  The result is validated against the same oracle and goldens as the fp32 path
