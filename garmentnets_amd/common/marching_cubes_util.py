@@ -112,79 +112,105 @@ ISO_STREAMS = int(os.environ.get("GARMENTNETS_ISO_STREAMS", "4"))     # concurre
 USE_ISO_GRAPHS = True      # wnf_batch_to_meshes_gpu replays a captured graph per garment slot (False: plain launches)
 
 
-def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
-    """wnf_to_mesh_gpu for a whole (B,Q,Q,Q) batch with ONE host synchronisation: the per-garment kernels (GGM, min/max, MC33 with a
-    generous vertex capacity; one HIP-graph replay per garment slot) are all queued first, the B (min, max, #verts, #faces) records come back in a single copy, then the
-    per-garment tails (slicing, vertex look-ups) are queued.  Every returned tensor is the caller's own (copied out of the slot buffers)
-    except 'ggm', the (Q,Q,Q) gradient-magnitude volume, which stays a view of slot b's buffer until the next call with the same
-    (slot, Q, level, sigma) -- clone it to keep it.  Same results and the same error contract as the one-garment function:
-    -> list of B entries, each a mesh dict or the exception (ValueError / RuntimeError) scikit-image would have raised."""
-    if gradient_direction not in ("ascent", "descent"):
-        raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % gradient_direction)
-    B, Q = wnf_all.shape[0], wnf_all.shape[-1]
-    spacing, level = 1 / (Q - 1), float(iso_surface_level)
-    cap_v = max(4096, int(6 * Q ** 2))
-    cap_f = 2 * cap_v + 64
-    vols, ggms, mcs, recs = [], [], [], []
-    dev = wnf_all.device
-    main = torch.cuda.current_stream(dev)
-    # the garments are independent and one 128^3 volume does not fill 256 CUs (GGM / classify / scan / emit are small grids with
-    # dependent launches in between): the slot graphs are replayed round-robin on a few side streams, forked from and joined to the
-    # caller's stream
-    lanes = _iso_streams(dev, min(ISO_STREAMS, B)) if (USE_ISO_GRAPHS and ISO_STREAMS > 1 and B > 1 and not torch.cuda.is_current_stream_capturing()) else []
-    ready = None
-    if lanes:
-        ready = torch.cuda.Event()
-        ready.record(main)
-    for b in range(B):
-        vol = wnf_all[b].float().contiguous()
-        vols.append(vol)
-        if USE_ISO_GRAPHS:                                         # results live in slot b's static buffers until its next replay
-            key = (b, Q, level, float(sigma), cap_v, str(vol.device))
-            if key not in _ISO_GRAPHS:
-                if len(_ISO_GRAPHS) >= 256:
-                    _ISO_GRAPHS.clear()
-                _ISO_GRAPHS[key] = _IsoGraph(Q, level, float(sigma), cap_v, cap_f, vol.device)
-            if lanes:
-                st = lanes[b % len(lanes)]
-                st.wait_event(ready)
-                with torch.cuda.stream(st):
+class IsoBatchJob:
+    """wnf_to_mesh_gpu for a batch, in two phases so that a caller can overlap it with the work that PRODUCES the volumes:
+    ``enqueue(wnf_part)`` queues the per-garment kernels (GGM, min/max, MC33 with a generous vertex capacity; one HIP-graph replay per
+    garment slot, round-robin on a few side streams forked from the caller's stream at that point) for the next garments of the batch
+    and returns at once; ``finish()`` joins the streams, fetches the B (min, max, #verts, #faces) records in ONE device-to-host copy and
+    queues the per-garment tails (slicing, vertex look-ups).  predict_batch enqueues the first half of the batch, decodes the second
+    half's lattice meanwhile, then enqueues that."""
+
+    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
+        if gradient_direction not in ("ascent", "descent"):
+            raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % gradient_direction)
+        self.Q, self.level, self.sigma, self.direction = int(Q), float(iso_surface_level), float(sigma), gradient_direction
+        self.cap_v = max(4096, int(6 * self.Q ** 2))
+        self.cap_f = 2 * self.cap_v + 64
+        self.vols, self.ggms, self.mcs, self.recs, self.lanes_used = [], [], [], [], []
+
+    def enqueue(self, wnf_part):
+        B0, Bp = len(self.vols), wnf_part.shape[0]
+        dev = wnf_part.device
+        main = torch.cuda.current_stream(dev)
+        # the garments are independent and one 128^3 volume does not fill 256 CUs (GGM / classify / scan / emit are small grids with
+        # dependent launches in between): the slot graphs are replayed round-robin on a few side streams
+        lanes = _iso_streams(dev, min(ISO_STREAMS, max(Bp, 1))) if (USE_ISO_GRAPHS and ISO_STREAMS > 1 and Bp > 1
+                                                                   and not torch.cuda.is_current_stream_capturing()) else []
+        ready = None
+        if lanes:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        for i in range(Bp):
+            b = B0 + i
+            vol = wnf_part[i].float().contiguous()
+            self.vols.append(vol)
+            if USE_ISO_GRAPHS:                                         # results live in slot b's static buffers until its next replay
+                key = (b, self.Q, self.level, self.sigma, self.cap_v, str(vol.device))
+                if key not in _ISO_GRAPHS:
+                    if len(_ISO_GRAPHS) >= 256:
+                        _ISO_GRAPHS.clear()
+                    _ISO_GRAPHS[key] = _IsoGraph(self.Q, self.level, self.sigma, self.cap_v, self.cap_f, vol.device)
+                if lanes:
+                    st = lanes[b % len(lanes)]
+                    st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        ggm, mc, rec = _ISO_GRAPHS[key](vol)
+                    if st not in self.lanes_used:
+                        self.lanes_used.append(st)
+                else:
                     ggm, mc, rec = _ISO_GRAPHS[key](vol)
             else:
-                ggm, mc, rec = _ISO_GRAPHS[key](vol)
-        else:
-            ggm = ops.ggm3d(vol, sigma)
-            mc = ops.mc33(vol, level, cap_v, cap_f)                # verts, faces, normals, values, counts (device)
-            rec = torch.cat((ops.minmax(vol).double(), mc[4].double()))
-        ggms.append(ggm)
-        mcs.append(mc)
-        recs.append(rec)
-    for st in lanes:
-        main.wait_stream(st)
-    host = torch.stack(recs).cpu().numpy()                         # the one synchronisation
-    out = []
-    for b in range(B):
-        vmin, vmax, nv, nf = float(host[b, 0]), float(host[b, 1]), int(host[b, 2]), int(host[b, 3])
-        if level < vmin or level > vmax:
-            out.append(ValueError("Surface level must be within volume data range."))
-            continue
-        if nv > cap_v or nf > cap_f:                               # rare: redo this garment with room for what it needs
-            try:
-                out.append(wnf_to_mesh_gpu(vols[b], level, sigma, gradient_direction))
-            except (ValueError, RuntimeError) as e:
-                out.append(e)
-            continue
-        if nv == 0:
-            out.append(RuntimeError("No surface found at the given iso value."))
-            continue
-        verts_vox, faces, normals, values = mcs[b][0][:nv], mcs[b][1][:nf], mcs[b][2][:nv], mcs[b][3][:nv]
-        if USE_ISO_GRAPHS:       # slot b's static buffers are overwritten by the next replay: hand out copies (a few MB per garment)
-            faces, normals, values = faces.clone(), normals.clone(), values.clone()
-        if gradient_direction == "descent":
-            faces = torch.flip(faces, dims=[1])
-        out.append(dict(verts=verts_vox.double() * spacing, verts_f32=ops.scale_verts(verts_vox, spacing), faces=faces, normals=normals,
-                        volume_value=values, volume_gradient_magnitude=ops.gather_nn(ggms[b], verts_vox, spacing), ggm=ggms[b]))
-    return out
+                ggm = ops.ggm3d(vol, self.sigma)
+                mc = ops.mc33(vol, self.level, self.cap_v, self.cap_f)  # verts, faces, normals, values, counts (device)
+                rec = torch.cat((ops.minmax(vol).double(), mc[4].double()))
+            self.ggms.append(ggm)
+            self.mcs.append(mc)
+            self.recs.append(rec)
+
+    def finish(self):
+        """-> list of B entries, each a mesh dict or the exception (ValueError / RuntimeError) scikit-image would have raised"""
+        if not self.vols:
+            return []
+        main = torch.cuda.current_stream(self.vols[0].device)
+        for st in self.lanes_used:
+            main.wait_stream(st)
+        host = torch.stack(self.recs).cpu().numpy()                    # the one synchronisation
+        spacing, level = 1 / (self.Q - 1), self.level
+        out = []
+        for b in range(len(self.vols)):
+            vmin, vmax, nv, nf = float(host[b, 0]), float(host[b, 1]), int(host[b, 2]), int(host[b, 3])
+            if level < vmin or level > vmax:
+                out.append(ValueError("Surface level must be within volume data range."))
+                continue
+            if nv > self.cap_v or nf > self.cap_f:                     # rare: redo this garment with room for what it needs
+                try:
+                    out.append(wnf_to_mesh_gpu(self.vols[b], level, self.sigma, self.direction))
+                except (ValueError, RuntimeError) as e:
+                    out.append(e)
+                continue
+            if nv == 0:
+                out.append(RuntimeError("No surface found at the given iso value."))
+                continue
+            mc = self.mcs[b]
+            verts_vox, faces, normals, values = mc[0][:nv], mc[1][:nf], mc[2][:nv], mc[3][:nv]
+            if USE_ISO_GRAPHS:   # slot b's static buffers are overwritten by the next replay: hand out copies (a few MB per garment)
+                faces, normals, values = faces.clone(), normals.clone(), values.clone()
+            if self.direction == "descent":
+                faces = torch.flip(faces, dims=[1])
+            out.append(dict(verts=verts_vox.double() * spacing, verts_f32=ops.scale_verts(verts_vox, spacing), faces=faces, normals=normals,
+                            volume_value=values, volume_gradient_magnitude=ops.gather_nn(self.ggms[b], verts_vox, spacing), ggm=self.ggms[b]))
+        return out
+
+
+def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
+    """wnf_to_mesh_gpu for a whole (B,Q,Q,Q) batch with ONE host synchronisation (IsoBatchJob: enqueue everything, finish).  Every
+    returned tensor is the caller's own (copied out of the slot buffers) except 'ggm', the (Q,Q,Q) gradient-magnitude volume, which
+    stays a view of slot b's buffer until the next call with the same (slot, Q, level, sigma) -- clone it to keep it.  Same results and
+    the same error contract as the one-garment function: -> list of B entries, each a mesh dict or the exception (ValueError /
+    RuntimeError) scikit-image would have raised."""
+    job = IsoBatchJob(wnf_all.shape[-1], iso_surface_level, sigma, gradient_direction)
+    job.enqueue(wnf_all)
+    return job.finish()
 
 
 def delete_invalid_verts(mc_verts, mc_faces, is_vert_on_surface):

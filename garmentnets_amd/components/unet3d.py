@@ -38,12 +38,15 @@ class SingleConv(PackedModule, nn.Sequential):
         wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
         return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse_flat=None):
+    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None):
         """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
         stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them.
-        sparse_flat: src0 is gn_grid_scatter's volume and this is the flat cell index of every scattered point -> occupancy-aware launch:
-        only the output tiles that can see an occupied cell go through the matrix cores, the rest are border-class constants taken from
-        a dense launch over a 3 x 3 x 3 all-zero volume with the same affine (bit-identical to the dense result, statistics included)."""
+        sparse: occupancy-aware launch (split-operand modes), a dict
+            flat      flat cell index of every point gn_grid_scatter scattered into the volume this layer descends from
+            reach     1: src0 IS that volume; 2: src0 is the output of the reach-1 layer (non-constant within one voxel of the cells)
+            small_in  (reach 2) the reach-1 layer's output over the 5 x 5 x 5 all-zero volume; this call adds 'small_out', its own
+        Only the output tiles that can see an occupied cell (within `reach`) go through the matrix cores; the rest are border-class
+        constants taken from a dense launch of this layer over the 5^3 zero volume with the same affine: bit-identical output."""
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None
@@ -59,17 +62,23 @@ class SingleConv(PackedModule, nn.Sequential):
             if key not in cache:
                 cache.clear()
                 cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
-            cout, sparse = self.conv.out_channels, {}
-            if (sparse_flat is not None and ops.SPARSE_FIRST_CONV and src1 is None and mode != ops.SPLIT_BF16X3 and cout % 128 == 0
-                    and src0.shape[-1] <= 384 and min(src0.shape[1:4]) >= 3):
-                B = src0.shape[0]
-                flags = ops.grid_tile_flags(sparse_flat, B, src0.shape[1:4])
-                zeros = torch.zeros((B, 3, 3, 3, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-                every = torch.ones((B, 1), dtype=torch.uint8, device=src0.device)
-                dummy = torch.zeros((B, 27, cout), dtype=torch.float32, device=src0.device)
-                kconst = ops.conv3d_gcr_split(zeros, None, a, d, cache[key], cout, relu=True, act_inv=act_inv, tile_active=every, kconst=dummy)
-                sparse = dict(tile_active=flags, kconst=kconst.reshape(B, 27, cout))
-            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sparse)
+            cout, sp = self.conv.out_channels, {}
+            if (sparse is not None and ops.SPARSE_FIRST_CONV and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
+                    and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]):
+                B, reach = src0.shape[0], int(sparse["reach"])
+                small_in = sparse.get("small_in")
+                if small_in is None:
+                    small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
+                every = torch.ones((B, 2), dtype=torch.uint8, device=src0.device)          # the 5^3 volume is two 4 x 8 x 8 tiles: all active
+                ncls = (2 * reach + 1) ** 3
+                dummy = torch.zeros((B, ncls, cout), dtype=torch.float32, device=src0.device)
+                small_out = ops.conv3d_gcr_split(small_in, None, a, d, cache[key], cout, relu=True, act_inv=act_inv, tile_active=every, kconst=dummy,
+                                                 kreach=reach)
+                pick = torch.tensor(list(range(reach)) + [2] + list(range(5 - reach, 5)), device=src0.device)   # class -> voxel of the 5^3 volume
+                kconst = small_out[:, pick][:, :, pick][:, :, :, pick].reshape(B, ncls, cout).contiguous()
+                sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
+                sparse["small_out"] = small_out
+            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
             return r if with_stats else (r, None)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
         if with_stats:
@@ -90,8 +99,11 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
     def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None):
-        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse_flat=sparse_flat)
-        return self.SingleConv2.run(y, None, st)
+        """sparse_flat: src0 is gn_grid_scatter's volume (flat cell index of every scattered point): both convolutions run occupancy-aware"""
+        sp1 = dict(flat=sparse_flat, reach=1) if sparse_flat is not None else None
+        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1)
+        sp2 = dict(flat=sparse_flat, reach=2, small_in=sp1["small_out"]) if (sp1 is not None and "small_out" in sp1) else None
+        return self.SingleConv2.run(y, None, st, sparse=sp2)
 
 
 class Encoder(nn.Module):

@@ -228,10 +228,10 @@ extern "C" int gn_grid_stats(const float *vol, const int32_t *flat_idx, int64_t 
 
 // ------------------------------------------------------------------------------------------------ tile occupancy
 // Which output tiles of a 3x3x3 convolution over the scattered volume can see an occupied cell: cell (d, h, w) reaches the outputs
-// d-1..d+1 (x h x w), i.e. up to 2 x 2 x 2 tiles of (TD, TH, TW) voxels.  flags[b][(ty * tiles_x + tx) * tiles_z + tz] = 1 -- the tile
+// d-1..d+1 (x h x w), i.e. up to 2 x 2 x 2 tiles of (TD, TH, TW) voxels (reach 1; reach 2 = the convolution behind it).  flags[b][(ty * tiles_x + tx) * tiles_z + tz] = 1 -- the tile
 // order of gn_conv3d_gcr_split's occupancy-aware launch (z fastest).  Everything else of that layer's output is a border-class constant.
 __global__ __launch_bounds__(256) void tile_flags_kernel(const int32_t *__restrict__ flat_idx, int64_t N, int G0, int G1, int G2, int TD, int TH,
-                                                         int TW, int tiles_z, int tiles_y, int tiles_x, unsigned char *__restrict__ flags) {
+                                                         int TW, int tiles_z, int tiles_y, int tiles_x, int reach, unsigned char *__restrict__ flags) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     int64_t c = flat_idx[p];
@@ -239,23 +239,23 @@ __global__ __launch_bounds__(256) void tile_flags_kernel(const int32_t *__restri
     const int h = (int)(c % G1); c /= G1;
     const int d = (int)(c % G0);
     const int64_t b = c / G0;
-    const int z0 = max(d - 1, 0) / TD, z1 = min(d + 1, G0 - 1) / TD;
-    const int y0 = max(h - 1, 0) / TH, y1 = min(h + 1, G1 - 1) / TH;
-    const int x0 = max(w - 1, 0) / TW, x1 = min(w + 1, G2 - 1) / TW;
+    const int z0 = max(d - reach, 0) / TD, z1 = min(d + reach, G0 - 1) / TD;
+    const int y0 = max(h - reach, 0) / TH, y1 = min(h + reach, G1 - 1) / TH;
+    const int x0 = max(w - reach, 0) / TW, x1 = min(w + reach, G2 - 1) / TW;
     unsigned char *f = flags + b * ((int64_t)tiles_z * tiles_y * tiles_x);
     for (int ty = y0; ty <= y1; ++ty)
         for (int tx = x0; tx <= x1; ++tx)
             for (int tz = z0; tz <= z1; ++tz) f[((int64_t)ty * tiles_x + tx) * tiles_z + tz] = 1;
 }
 
-extern "C" int gn_grid_tile_flags(const int32_t *flat_idx, int64_t N, int B, int G0, int G1, int G2, unsigned char *flags, void *stream) {
-    GN_REQUIRE(N >= 0 && B >= 0 && G0 > 0 && G1 > 0 && G2 > 0, "gn_grid_tile_flags: bad sizes");
+extern "C" int gn_grid_tile_flags(const int32_t *flat_idx, int64_t N, int B, int G0, int G1, int G2, int reach, unsigned char *flags, void *stream) {
+    GN_REQUIRE(N >= 0 && B >= 0 && G0 > 0 && G1 > 0 && G2 > 0 && reach >= 1 && reach <= 4, "gn_grid_tile_flags: bad sizes");
     const int TD = 4, TH = 8, TW = 8;               // the output tile of csrc/unet_split.hip (SP_TZ, SP_TY, SP_TX)
     const int tz = (int)gn_cdiv(G0, TD), ty = (int)gn_cdiv(G1, TH), tx = (int)gn_cdiv(G2, TW);
     hipStream_t st = gn_stream(stream);
     GN_HIP(hipMemsetAsync(flags, 0, (size_t)B * tz * ty * tx, st), "gn_grid_tile_flags");
     if (N == 0) return GN_OK;
-    hipLaunchKernelGGL(tile_flags_kernel, dim3((unsigned)gn_cdiv(N, 256)), dim3(256), 0, st, flat_idx, N, G0, G1, G2, TD, TH, TW, tz, ty, tx, flags);
+    hipLaunchKernelGGL(tile_flags_kernel, dim3((unsigned)gn_cdiv(N, 256)), dim3(256), 0, st, flat_idx, N, G0, G1, G2, TD, TH, TW, tz, ty, tx, reach, flags);
     GN_LAUNCH_CHECK("gn_grid_tile_flags");
     return GN_OK;
 }

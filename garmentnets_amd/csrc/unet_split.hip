@@ -37,6 +37,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SP_ABL 0     // dev-only ablation switches (tools/dev/ab_split_abl.py); 0 in the product build
 #endif
 
+// border class of coordinate z on an axis of length D for reach r (see SplitArgs::kreach)
+__device__ __forceinline__ int sp_axis_class(int z, int D, int r) { return z < r ? z : (z >= D - r ? 2 * r - (D - 1 - z) : r); }
+
 struct SplitArgs {
     const float *src0;
     const float *src1;
@@ -55,6 +58,9 @@ struct SplitArgs {
     // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
     const unsigned char *tile_active;
     const float *kconst;
+    int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
+                              // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
+                              // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
 };
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     const int n0 = cb * CT;
     const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
+    const bool inactive = p.tile_active && !p.tile_active[(int64_t)b * (tiles_z * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tiles_z + tz];
 
     f32x16s acc[NF][NT], tot[NF][NT];               // fragment f = 2 m + t: z-slice wave + 4 m, y half t
 #pragma unroll
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
+    if (!inactive) {                                // (workgroup-uniform: an inactive tile issues no DMA, no staging, no MFMA)
     const int abase = HL::at(wave, r >> 3, r & 7) + 16 * h;                          // bytes; plane pl at +32*pl
     constexpr int AF1 = 4 * HL::ROWP, AFZ = 4 * SP_HY * HL::ROWP;                       // y half, second z-slice
     const int nslices = Cin / SP_KS;
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     }
 #undef SP_ISSUE_B
     GN_WAIT_VM_LGKM0(0);                            // the pad-step DMAs must land before the LDS goes away
+    }
     __syncthreads();                                // the epilogue reuses the halo as scratch
     // ---- epilogue (identical to the fp32 kernel)
     float ssum[NT], ssq[NT];
@@ -368,8 +377,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
-                    float v = __fmul_rn(tot[f][u][q], osc);
-                    if (p.relu) v = gn_relu(v);
+                    float v;
+                    if (inactive) {                  // the finished value a dense launch gives a voxel of this border class
+                        const int nc = 2 * p.kreach + 1;
+                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
+                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
+                    } else {
+                        v = __fmul_rn(tot[f][u][q], osc);
+                        if (p.relu) v = gn_relu(v);
+                    }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += v;
                     ssq[u] = fmaf(v, v, ssq[u]);
@@ -624,8 +640,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v;
                     if (inactive) {                  // the finished value (scale and ReLU applied) a dense launch gives a voxel of this border class
-                        const int cls = ((gz == 0 ? 0 : (gz == p.D - 1 ? 2 : 1)) * 3 + (gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1))) * 3 + (gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1));
-                        v = p.kconst[((int64_t)b * 27 + cls) * p.Cout + n];
+                        const int nc = 2 * p.kreach + 1;
+                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
+                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(tot[t][u][q], osc);
                         if (p.relu) v = gn_relu(v);
@@ -680,7 +697,7 @@ static bool gn_ztwin_enabled() {
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
                                    int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                                   const float *kconst, void *stream) {
+                                   const float *kconst, int kreach, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -696,13 +713,13 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
-    p.tile_active = tile_active; p.kconst = kconst;
+    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach;
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
     const int Cin_total = C0 + C1;
-    const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
+    const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024) && !tile_active;
     // (MT = 2, the tall 8 x 8 x 8 tile, was measured on the 32-wide layers: 327-347 TFLOP/s vs 340 for MT = 1 -- its synchronous
     //  staging phase is 29 % of the kernel -- so it is not dispatched)
 #define SP_LAUNCH(P_, F16_)                                                                                                    \
@@ -712,9 +729,12 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
         gn_note_kernel(wide ? "conv3d_split_kernel<2, " #P_ ", " #F16_ ", 1>" : "conv3d_split_kernel<1, " #P_ ", " #F16_ ", 1>"); \
     } while (0)
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
+    // an occupancy-aware launch pins the kernel variant (so that the border-class constants, taken from a launch over a tiny volume, come
+    // out of the same instruction stream): the 128-wide variant when Cout % 128 == 0, conv3d_split_kernel<1> otherwise
     const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && ((int64_t)tiles * (Cout / 128) * B >= 512 || tile_active);
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
-    GN_REQUIRE(!tile_active || (wide128 && D >= 3 && H >= 3 && W >= 3), "gn_conv3d_gcr_split: the occupancy-aware launch needs the 128-wide variant (two-plane mode, Cout %% 128 == 0, Cin <= 384) and dims >= 3");
+    GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
+               "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
     // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
     const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
     const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();

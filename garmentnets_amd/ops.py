@@ -351,26 +351,27 @@ def pack_conv_weight_split(w, mode):
     return SplitPack(pk.contiguous().view(torch.int16), mode, (1.0 / scale).contiguous().to(w.device))
 
 
-def grid_tile_flags(flat_idx, B, grid_shape):
-    """uint8 [B][tiles]: the 4 x 8 x 8 output tiles of a 3x3x3 conv over the scattered volume that can see an occupied cell"""
+def grid_tile_flags(flat_idx, B, grid_shape, reach=1):
+    """uint8 [B][tiles]: the 4 x 8 x 8 output tiles of a 3x3x3 conv over the scattered volume that can see an occupied cell (reach 1),
+    or of the conv behind it (reach 2)"""
     g0, g1, g2 = [int(v) for v in grid_shape]
     tiles = -(-g0 // 4) * -(-g1 // 8) * -(-g2 // 8)
     flags = torch.empty((B, tiles), dtype=torch.uint8, device=flat_idx.device)
-    _lib.call("gn_grid_tile_flags", _p(_chk(flat_idx, _i32, "flat_idx")), flat_idx.numel(), B, g0, g1, g2, _p(flags), _stream())
+    _lib.call("gn_grid_tile_flags", _p(_chk(flat_idx, _i32, "flat_idx")), flat_idx.numel(), B, g0, g1, g2, int(reach), _p(flags), _stream())
     return flags
 
 
-# occupancy-aware first UNet convolution (exact: bit-identical to the dense launch); "0" = always dense
+# occupancy-aware first two UNet convolutions (exact: bit-identical to the dense launch); "0" = always dense
 SPARSE_FIRST_CONV = os.environ.get("GARMENTNETS_SPARSE_CONV", "1") != "0"
 
 
-def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None):
+def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
     _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
-              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), _stream())
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

@@ -13,6 +13,7 @@ is out of scope, so inputs are a checkpoint (or seeded synthetic 
 """
 import argparse
 import json
+import os
 import time
 
 import numpy as np
@@ -34,6 +35,7 @@ def nan_placeholder(device):
 
 
 _FALLBACKS = {"count": 0}
+OVERLAP_ISO = os.environ.get("GARMENTNETS_OVERLAP_ISO", "1") != "0"    # first half's iso-surface graphs beside the second half's lattice decode
 
 
 def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
@@ -69,12 +71,26 @@ def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_s
         unet3d_result = model.unet3d_forward(pointnet2_result)
         nocs_data = pointnet2_result["nocs_data"]
         B = nocs_data.num_graphs
-        wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
+        # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first).  The
+        # lattice is decoded in two halves: the first half's GGM / marching-cubes graphs (small, latency-bound grids on side streams) run
+        # beside the second half's decoder MLP (matrix-core bound)
+        meshes = None
+        if auto_level or B < 4 or not OVERLAP_ISO:
+            wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
+            if not auto_level:
+                meshes = mcu.wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level, gradient_sigma, gradient_direction)
+        else:
+            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction)
+            parts = []
+            for b0, b1 in ((0, B // 2), (B // 2, B)):
+                part = model.volume_lattice_forward(unet3d_result.select(b0, b1), volume_size)["pred_volume"]
+                job.enqueue(part)
+                parts.append(part)
+            wnf_all = torch.cat(parts)
+            meshes = job.finish()
         bad = torch.isnan(wnf_all).any()             # read by the caller after the batch's own host synchronisation
         ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
         results = []
-        # iso-surfaces of the whole batch with one host synchronisation (fixed level); auto_level needs each volume's range first
-        meshes = None if auto_level else mcu.wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level, gradient_sigma, gradient_direction)
         if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
             return None, True
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)

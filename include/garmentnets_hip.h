@@ -132,8 +132,9 @@ int gn_grid_scatter(const float *src, int lds, const int32_t *flat_idx, int64_t 
                     float *vol, int32_t *count_ws, void *ws, size_t ws_bytes, int vol_is_zeroed, void *stream);
 
 /* Output tiles (4 x 8 x 8 voxels, the tiling of gn_conv3d_gcr_split) of a 3x3x3 convolution over the scattered volume that can see an
- * occupied cell: flags [B][tiles_y * tiles_x * tiles_z] bytes (zeroed inside), index (ty * tiles_x + tx) * tiles_z + tz. */
-int gn_grid_tile_flags(const int32_t *flat_idx, int64_t N, int B, int G0, int G1, int G2, unsigned char *flags, void *stream);
+ * occupied cell: flags [B][tiles_y * tiles_x * tiles_z] bytes (zeroed inside), index (ty * tiles_x + tx) * tiles_z + tz.  reach = 1 for the
+ * convolution that reads the scattered volume, 2 for the one behind it (its input is non-constant within one voxel of the cells). */
+int gn_grid_tile_flags(const int32_t *flat_idx, int64_t N, int B, int G0, int G1, int G2, int reach, unsigned char *flags, void *stream);
 
 /* Per-(sample, channel) sum / sum of squares of a scattered volume computed from its OCCUPIED cells only (all other
  * cells are zero): the GroupNorm statistics of the first UNet layer without reading the (mostly empty) volume.
@@ -188,14 +189,15 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
 #define GN_SPLIT_F16X2 4
 /* Occupancy-aware launch (the layer whose input is gn_grid_scatter's volume, > 99 % empty for 6000 points in 128^3 cells):
  * tile_active (NULL, or [B][tiles] bytes from gn_grid_tile_flags) marks the 4 x 8 x 8 output tiles whose halo holds an occupied cell;
- * every other tile's outputs are border-class constants kconst [B][27][Cout] (class (cz*3 + cy)*3 + cx, c = 0 first voxel of the
- * axis / 1 interior / 2 last voxel; the FINISHED values a dense launch produces there -- garmentnets_amd takes them from a dense
- * launch over a small all-zero volume with the same affine) and are stored without touching the matrix cores.  Bit-identical to
- * the dense launch, statistics included.  128-wide variant only (two-plane modes, Cout % 128 == 0, C0 + C1 <= 384). */
+ * every other tile's outputs are border-class constants kconst [B][(2r+1)^3][Cout], r = kreach (class (cz*n + cy)*n + cx with, per
+ * axis, c = z for z < r, 2r - (D-1-z) for z >= D-r, r otherwise; the FINISHED values a dense launch produces there -- garmentnets_amd
+ * takes them from dense launches of the same layers over a 5 x 5 x 5 all-zero volume with the same affines) and are stored without
+ * touching the matrix cores.  kreach = 1: the layer fed by the scattered volume; 2: the layer behind it.  The output is bit-identical
+ * to the dense launch.  Two-plane modes only; the launch pins the kernel variant (128-wide for Cout % 128 == 0, else the 32-wide one). */
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                         const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H, int W,
                         int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                        const float *kconst, void *stream);
+                        const float *kconst, int kreach, void *stream);
 
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */

@@ -959,35 +959,41 @@ def test_sa_fused_runs_in_the_pipeline(golden_dir):
 # ------------------------------------------------------------------------------------------------ occupancy-aware first convolution
 @pytest.mark.parametrize("G,mode", [(32, 4), (36, 4), (20, 2)])
 def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
-    """the first UNet convolution on a scattered volume: only the tiles that can see an occupied cell go through the matrix cores, the
-    rest are border-class constants (csrc/unet_split.hip tile_active / kconst).  The output must equal the dense launch bit for bit (the
-    epilogue statistics up to the order of their fp64 atomics): occupied cells in corners / on faces / in the interior, a garment without any point, a grid that is not a
-    multiple of the tile."""
-    from garmentnets_amd.components.unet3d import SingleConv
+    """the first TWO UNet convolutions behind a scattered volume (the encoder's first DoubleConv, 128 -> 128 -> 32): only the tiles that
+    can see an occupied cell (within 1 voxel for the first layer, 2 for the second) go through the matrix cores, the rest are
+    border-class constants (csrc/unet_split.hip tile_active / kconst / kreach).  Both outputs must equal the dense launches bit for
+    bit (the epilogue statistics up to the order of their fp64 atomics): occupied cells in corners / on faces / in the interior, a
+    garment without any point, a grid that is not a multiple of the tile."""
+    from garmentnets_amd.components.unet3d import DoubleConv
     g = torch.Generator().manual_seed(G)
-    B, C, Cout = 3, 128, 128
+    B, C = 3, 128
     cells = [torch.tensor([[0, 0, 0], [G - 1, G - 1, G - 1], [0, G - 1, 5], [G // 2, G // 2, G // 2], [G // 2, G // 2, G // 2 + 1], [3, 8, 9], [4, 7, 8]]),
              torch.zeros((0, 3), dtype=torch.int64),
              torch.randint(0, G, (200, 3), generator=g)]
     flat = torch.cat([(((b * G + c[:, 0]) * G + c[:, 1]) * G + c[:, 2]) for b, c in enumerate(cells)]).to(torch.int32)
     feats = torch.randn(flat.numel(), C, generator=g)
     vol, stats = ops.grid_scatter(feats.to(DEV), flat.to(DEV), B, (G, G, G), "max", with_stats=True)
-    conv = SingleConv(C, Cout)
-    sd = {k: S.synthetic_tensor("c." + k, tuple(v.shape), 1) for k, v in conv.state_dict().items()}
-    conv.load_state_dict(sd)
-    conv = conv.to(DEV)
+    dc = DoubleConv(C, 32, encoder=True)                                   # 128 -> 128 -> 32, the shipped encoders.0
+    dc.load_state_dict({k: S.synthetic_tensor("c." + k, tuple(v.shape), 1) for k, v in dc.state_dict().items()})
+    dc = dc.to(DEV)
     try:
         saved_mode, saved_sp = ops.CONV_MODE, ops.SPARSE_FIRST_CONV
         ops.CONV_MODE, ops.SPARSE_FIRST_CONV = mode, True
-        y_s, (s_s, q_s, V) = conv.run(vol, None, stats, None, sparse_flat=flat.to(DEV))
-        flags = ops.grid_tile_flags(flat.to(DEV), B, (G, G, G))
-        y_d, (s_d, q_d, _) = conv.run(vol, None, stats, None)
+        sp1 = dict(flat=flat.to(DEV), reach=1)
+        y1_s, st1_s = dc.SingleConv1.run(vol, None, stats, None, sparse=sp1)
+        y2_s, st2_s = dc.SingleConv2.run(y1_s, None, st1_s, sparse=dict(flat=flat.to(DEV), reach=2, small_in=sp1["small_out"]))
+        both_s, _ = dc.run(vol, None, stats, None, sparse_flat=flat.to(DEV))
+        ops.SPARSE_FIRST_CONV = False
+        y1_d, st1_d = dc.SingleConv1.run(vol, None, stats, None)
+        y2_d, st2_d = dc.SingleConv2.run(y1_d, None, st1_d)
     finally:
         ops.CONV_MODE, ops.SPARSE_FIRST_CONV = saved_mode, saved_sp
-    active = flags.sum(dim=1).tolist()
-    print(f"G={G} mode={mode}: active tiles per garment {active} of {flags.shape[1]}")
-    assert active[1] == 0 and 0 < active[0] < flags.shape[1]
-    assert torch.equal(y_s, y_d)
+    f1, f2 = ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 1), ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 2)
+    a1, a2 = f1.sum(dim=1).tolist(), f2.sum(dim=1).tolist()
+    print(f"G={G} mode={mode}: active tiles per garment, layer 1 {a1} / layer 2 {a2} of {f1.shape[1]}")
+    assert a1[1] == 0 and a2[1] == 0 and 0 < a1[0] <= a2[0] < f1.shape[1] and bool((f2 >= f1).all())
+    assert torch.equal(y1_s, y1_d) and torch.equal(y2_s, y2_d) and torch.equal(both_s, y2_d)
     # the statistics are fp64 atomic sums of identical per-tile fp32 partials: equal up to the order of the fp64 additions (1 ulp)
-    assert float(((s_s - s_d).abs() / s_d.abs().clamp_min(1e-30)).max()) <= 1e-13 and float(((q_s - q_d).abs() / q_d.abs().clamp_min(1e-30)).max()) <= 1e-13
-    assert bool(torch.isfinite(y_s).all()) and float(y_s.abs().max()) > 0
+    for (s_s, q_s, _), (s_d, q_d, _) in ((st1_s, st1_d), (st2_s, st2_d)):
+        assert float(((s_s - s_d).abs() / s_d.abs().clamp_min(1e-30)).max()) <= 1e-13 and float(((q_s - q_d).abs() / q_d.abs().clamp_min(1e-30)).max()) <= 1e-13
+    assert bool(torch.isfinite(y2_s).all()) and float(y2_s.abs().max()) > 0
