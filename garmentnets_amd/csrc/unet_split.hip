@@ -58,6 +58,7 @@ struct SplitArgs {
     // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
     const unsigned char *tile_active;
     const float *kconst;
+    int exp;                  // dev-only experiment bits (GARMENTNETS_CONV_EXP; 0 in production)
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
@@ -422,9 +423,17 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 // wave groups take two z-ADJACENT 4 x 8 x 8 tiles (one 8 x 8 x 8 block, ONE 10 x 10 x 10 halo: 1.95 staged voxels per output voxel
 // instead of 2.34) of the SAME 32 output channels and share every DMA'd B fragment.  What it buys over conv3d_split_kernel<1,...>:
 // the staging of slice s+1 rides inside the matrix-core stream of slice s (double-buffered halo) instead of stopping it.
+// SPW_PIPE = 1 (dev build): B fragments double-buffered one tap ahead (read right after the hand-over, consumed next tap).  The 16 extra
+// registers only fit next to a SINGLE-level accumulation (no per-slice `tot`): measured 431 vs 417.5 TFLOP/s-eq (+3.2 %) on 128 -> 128
+// at 128^3, but the error against fp64 grows from 3.4-3.8e-6 to 3.1-9.4e-6 (above the fp32-MFMA kernel's in two of five shapes) -- not
+// worth it; the product build keeps the two-level summation.
+#ifndef SPW_PIPE
+#define SPW_PIPE 0
+#endif
 template <int P, bool F16, bool ZTWIN>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
     static_assert(P == 2, "the wide variant is sized for the two-plane modes");
+    constexpr bool PIPE = SPW_PIPE != 0, TWOLEVEL = !PIPE;
     constexpr int NT = ZTWIN ? 1 : 2;
     constexpr int TZ = ZTWIN ? 2 * SP_TZ : SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
     constexpr int CW = ZTWIN ? 32 : 128;            // output channels per workgroup
@@ -529,6 +538,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
         }
     };
 
+    if ((p.exp & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half (MI355X_MICROARCH.md)
     // slice 0 synchronously
     issue_rows(0);
     GN_WAIT_VM_LGKM0(0);
@@ -541,11 +551,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     constexpr int AF1 = 4 * HL::ROWP;
     const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (ZTWIN ? 0 : cg * NT * P) * 1024 + lane * 16;
     int jcur = 0;
-    uint4 bf[NT][P];                                // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
+    uint4 bf[NT][P], nbf[NT][P];                    // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (u * P + i) * 1024);
+        for (int i = 0; i < P; ++i) nbf[u][i] = bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (u * P + i) * 1024);
     for (int s = 0; s < nslices; ++s) {
         const unsigned char *const halo = smem + (s & 1) * HALO_BYTES;
         const int sn = s + 1 < nslices ? s + 1 : s;
@@ -559,6 +569,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
         for (int tap = 0; tap < 27; ++tap, ++jcur) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
+            if (PIPE) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) bf[u][i] = nbf[u][i];
+            }
             // hand-over: step j+1's fragments have landed for everybody (they are read at the END of this tap, into the registers the
             // MFMAs of this tap have just consumed: no register double buffer, no LDS latency after the barrier) and everybody is done
             // with step j-1's slot.  VM queue, oldest first: fragment steps j+1 .. j+DEPTH-2 and, for taps 1-2, the NIT row loads
@@ -594,6 +610,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                     na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + toff + i * 32);
                 }
             }
+            if (PIPE) {          // step j+1 landed for everybody before this tap's hand-over: fetch it now, a whole tap before its MFMAs
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
+            }
             if (tap == 0) issue_rows(sn);                                        // always (uniform wait counts); unused after the last slice
             __builtin_amdgcn_sched_barrier(0);
 #define SPW_PROD(IA, IB)                                                                                                       \
@@ -606,18 +628,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             SPW_PROD(0, 1) SPW_PROD(0, 0)
 #undef SPW_PROD
             __builtin_amdgcn_sched_barrier(0);
+            if (!PIPE) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+                for (int u = 0; u < NT; ++u)
 #pragma unroll
-                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (TWOLEVEL) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+                for (int u = 0; u < NT; ++u)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
+                    for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
+        }
     }
 #undef SPW_ISSUE_B
     GN_WAIT_VM_LGKM0(0);
@@ -644,7 +670,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                         const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
-                        v = __fmul_rn(tot[t][u][q], osc);
+                        v = __fmul_rn(TWOLEVEL ? tot[t][u][q] : acc[t][u][q], osc);
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
@@ -714,6 +740,7 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
     p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach;
+    { static const int e = [] { const char *v = getenv("GARMENTNETS_CONV_EXP"); return v ? atoi(v) : 0; }(); p.exp = e; }
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
