@@ -58,7 +58,6 @@ struct SplitArgs {
     // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
     const unsigned char *tile_active;
     const float *kconst;
-    int exp;                  // dev-only experiment bits (GARMENTNETS_CONV_EXP; 0 in production)
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
@@ -538,7 +537,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
         }
     };
 
-    if ((p.exp & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);     // experiment: static priority for the younger half (MI355X_MICROARCH.md)
     // slice 0 synchronously
     issue_rows(0);
     GN_WAIT_VM_LGKM0(0);
@@ -740,7 +738,6 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
     p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach;
-    { static const int e = [] { const char *v = getenv("GARMENTNETS_CONV_EXP"); return v ? atoi(v) : 0; }(); p.exp = e; }
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
