@@ -301,9 +301,13 @@ def main():
     rank, local_rank, world = parallel.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    parallel.init(backend="nccl", device=dev)      # "nccl" is RCCL on ROCm; no-op for one process
+    # (GARMENTNETS_DIST_BACKEND=gloo: control-flow smoke test of the N > 1 path on a box with fewer GPUs than ranks -- ranks share devices)
+    backend = os.environ.get("GARMENTNETS_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    parallel.init(backend=backend, device=dev)     # "nccl" is RCCL on ROCm; no-op for one process
+    metrics_dev = dev if backend == "nccl" else "cpu"
 
     from garmentnets_amd import ops, synthetic as S
     from garmentnets_amd.batch import Batch
@@ -459,7 +463,7 @@ def main():
     n_local = (hi - lo) * args.steps
     occ_t = [occupancy[k].get(f, 0.0) for k, f in (("synthetic_clouds", "seconds"), ("realistic_occupancy", "seconds"), ("realistic_occupancy", "seconds_dense"))] \
         if occupancy else [0.0, 0.0, 0.0]
-    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0] + occ_t, device=dev)
+    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0] + occ_t, device=metrics_dev)
     if rank == 0:
         value, tmax = parallel.aggregate_throughput(per_rank)
         garments = sum(r[0] for r in per_rank)
