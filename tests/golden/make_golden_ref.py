@@ -6,8 +6,12 @@ Run:  python tests/golden/make_golden_ref.py          (needs /root/reference; ne
 The reference (/root/reference) imports only with sys.modules stubs for its absent third-party packages
 (SURVEY.md Appendix D).  The five torch_geometric callables + torch_scatter.scatter are provided by stubs
 that implement the *pinned definitions* of DESIGN.md section 3 (PyG/torch_cluster/torch_scatter are not
-installable offline), written here in edge-list / generic-torch form, i.e. independently of both the
-oracle's dense formulation and the HIP kernels.  Everything else -- MLP, PointNet2NOCS composition, heads,
+installable offline).  PointConv / global_max_pool / scatter are written here in edge-list / generic-torch form,
+independently of the oracle's dense formulation and of the HIP kernels; fps, radius and knn_interpolate, however, ARE
+the oracle's own C functions (oracle.fps / ball_query / knn_interpolate, lines 36-46 and 85-86 below): for those three
+the goldens pin the COMPOSITION around them, not the operators -- tests/test_oracle_golden.py::
+test_point_ops_against_plain_torch is what stands between a shared misreading of torch_cluster and a green suite.
+Everything else -- MLP, PointNet2NOCS composition, heads,
 NOCS arg-max post-processing, VirtualGrid index maths, VolumeFeatureAggregator, Abstract3DUNet,
 ImplicitWNFDecoder, the 64^3-chunk decode loop -- is the reference's code executing on real torch.
 
