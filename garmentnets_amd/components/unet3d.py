@@ -74,10 +74,28 @@ class SingleConv(PackedModule, nn.Sequential):
                 dummy = torch.zeros((B, ncls, cout), dtype=torch.float32, device=src0.device)
                 small_out = ops.conv3d_gcr_split(small_in, None, a, d, cache[key], cout, relu=True, act_inv=act_inv, tile_active=every, kconst=dummy,
                                                  kreach=reach)
-                pick = torch.tensor(list(range(reach)) + [2] + list(range(5 - reach, 5)), device=src0.device)   # class -> voxel of the 5^3 volume
-                kconst = small_out[:, pick][:, :, pick][:, :, :, pick].reshape(B, ncls, cout).contiguous()
+                # class -> voxel of the 5^3 volume: reach 1 = voxels 0 / 2 / 4 per axis, reach 2 = all five (strided views: nothing is
+                # copied from the host, so the path can be captured into a HIP graph)
+                step = 2 if reach == 1 else 1
+                kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
                 sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
                 sparse["small_out"] = small_out
+            if (src1 is not None and ops.POLYPHASE_UPCONV and mode != ops.SPLIT_BF16X3 and (8 * cout) % 128 == 0 and 8 * cout <= 1024
+                    and src1.shape[-1] <= 384):
+                # polyphase form: the nearest-upsampled channels as a 2x2x2-tap convolution per output parity class on the COARSE volume
+                # (8/27 of their MACs, staged once per coarse voxel instead of once per fine voxel), added in the fine launch's epilogue
+                c0 = src0.shape[-1]
+                pkey = ("poly",) + key + (c0,)
+                if pkey not in cache:
+                    w0, wm, mask = ops.polyphase_weights(self.conv.weight, c0)
+                    dev = self.conv.weight.device
+                    cache[pkey] = (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_conv_weight_split(wm, mode).to(dev), mask.to(dev))
+                pk0, pkm, mask = cache[pkey]
+                part = ops.conv3d_gcr_split(src1, None, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, 8 * cout, relu=False, act_inv=act_inv,
+                                            tapmask=mask)
+                r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
+                                         act_inv=act_inv, partial=part)
+                return r if with_stats else (r, None)
             r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
             return r if with_stats else (r, None)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)

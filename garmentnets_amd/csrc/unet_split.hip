@@ -58,6 +58,13 @@ struct SplitArgs {
     // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
     const unsigned char *tile_active;
     const float *kconst;
+    // polyphase form of a layer whose second source is nearest-upsampled (the decoders' first convolutions): the upsampled part is a
+    // 2x2x2-tap convolution per output parity class on the COARSE volume (8/27 of the MACs), computed by a separate launch over the coarse
+    // source with N' = 8 * Cout class-blocked output channels and merged weights; tapmask[tap] bit i = 32-wide column block i has non-zero
+    // weights at this tap (the 128-wide variant skips the other MFMAs); the fine launch over the first source then adds
+    // partial[b][z>>1][y>>1][x>>1][((z&1)*4 + (y&1)*2 + (x&1)) * Cout + n] before the ReLU.
+    const unsigned *tapmask;
+    const float *partial;
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(tot[f][u][q], osc);
+                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
@@ -429,9 +437,10 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 #ifndef SPW_PIPE
 #define SPW_PIPE 0
 #endif
-template <int P, bool F16, bool ZTWIN>
+template <int P, bool F16, bool ZTWIN, bool MASKED = false>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
     static_assert(P == 2, "the wide variant is sized for the two-plane modes");
+    static_assert(!(ZTWIN && MASKED), "the tap mask belongs to the 128-wide form");
     constexpr bool PIPE = SPW_PIPE != 0, TWOLEVEL = !PIPE;
     constexpr int NT = ZTWIN ? 1 : 2;
     constexpr int TZ = ZTWIN ? 2 * SP_TZ : SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
@@ -616,10 +625,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             }
             if (tap == 0) issue_rows(sn);                                        // always (uniform wait counts); unused after the last slice
             __builtin_amdgcn_sched_barrier(0);
+            // MASKED (class-blocked polyphase weights): only the column blocks with non-zero weights at this tap are multiplied
+            const unsigned tm = MASKED ? (p.tapmask[tap] >> (cb * 4 + cg * 2)) & 3u : 3u;
 #define SPW_PROD(IA, IB)                                                                                                       \
             _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
-                acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                         \
-                acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                         \
+                if (!MASKED || ((tm >> u) & 1u)) {                                                                             \
+                    acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                     \
+                    acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                     \
+                }                                                                                                              \
             }
             SPW_PROD(1, 0)
             if (tap >= 8 && tap < 8 + NIT && s + 1 < nslices) convert_row(tap - 8, sn, (s + 1) & 1);
@@ -669,6 +682,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(TWOLEVEL ? tot[t][u][q] : acc[t][u][q], osc);
+                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
@@ -721,7 +735,7 @@ static bool gn_ztwin_enabled() {
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
                                    int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                                   const float *kconst, int kreach, void *stream) {
+                                   const float *kconst, int kreach, const unsigned *tapmask, const float *partial, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -737,7 +751,9 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
-    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach;
+    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach; p.tapmask = tapmask; p.partial = partial;
+    GN_REQUIRE(!partial || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: a polyphase partial needs even dims");
+    GN_REQUIRE(!(tapmask && tile_active), "gn_conv3d_gcr_split: tapmask and tile_active are exclusive");
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
@@ -762,7 +778,11 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
     const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
     const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
-    if (wide128) {
+    if (wide128 && tapmask && Cout <= 1024) {   // (the mask is a hint: every other variant multiplies the zero blocks too)
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false, true>" : "conv3d_split_wide_kernel<2, false, false, true>");
+    } else if (wide128) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false>" : "conv3d_split_wide_kernel<2, false, false>");

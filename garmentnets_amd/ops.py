@@ -365,13 +365,40 @@ def grid_tile_flags(flat_idx, B, grid_shape, reach=1):
 SPARSE_FIRST_CONV = os.environ.get("GARMENTNETS_SPARSE_CONV", "1") != "0"
 
 
-def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1):
+# polyphase form of the decoders' first convolutions (nearest-upsampled second source): "0" = literal form (src1 read at half resolution)
+POLYPHASE_UPCONV = os.environ.get("GARMENTNETS_POLYPHASE", "1") != "0"
+
+
+def polyphase_weights(w, c0):
+    """nn.Conv3d weight (Cout, C0 + C1, 3,3,3) of a layer that reads cat((skip [C0 ch], upsample_nearest_x2(x) [C1 ch])) ->
+    (w0 (Cout, C0, 3,3,3): the full-resolution part unchanged;
+     wm (8 * Cout, C1, 3,3,3): the upsampled part as a convolution over the COARSE volume, output channel (class, n), class = 4 pz + 2 py + px
+         the parity of the fine output voxel: a fine tap d in {-1, 0, +1} of an even voxel lands on coarse offset {-1, 0, 0}, of an odd voxel
+         on {0, 0, +1}, so the 27 fine taps merge (sums of weights, fp64) into 2 x 2 x 2 coarse taps per class -- exact algebra;
+     tapmask int32 [27]: bit i = 32-wide output block i of wm has a non-zero weight at tap (kd * 3 + kh) * 3 + kw)."""
+    w = w.detach().double().cpu()
+    cout = w.shape[0]
+    w0, w1 = w[:, :c0].float(), w[:, c0:]
+    M = torch.zeros(2, 3, 3, dtype=torch.float64)            # [parity][coarse tap][fine tap]
+    M[0, 0, 0] = M[0, 1, 1] = M[0, 1, 2] = 1.0
+    M[1, 1, 0] = M[1, 1, 1] = M[1, 2, 2] = 1.0
+    blocks = [torch.einsum("az,by,cx,nkzyx->nkabc", M[pz], M[py], M[px], w1) for pz in (0, 1) for py in (0, 1) for px in (0, 1)]
+    wm = torch.cat(blocks, dim=0).float()                    # (8 * Cout, C1, 3, 3, 3)
+    nz = (wm.reshape(8 * cout // 32, 32, -1, 27) != 0).any(dim=2).any(dim=1)       # [block][tap]
+    mask = torch.zeros(27, dtype=torch.int64)
+    for blk in range(nz.shape[0]):
+        mask |= nz[blk].to(torch.int64) << blk
+    return w0.contiguous(), wm.contiguous(), mask.to(torch.int32)
+
+
+def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1,
+                     tapmask=None, partial=None):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
     _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
-              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _stream())
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(tapmask), _p(partial), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

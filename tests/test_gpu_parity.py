@@ -997,3 +997,46 @@ def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
     for (s_s, q_s, _), (s_d, q_d, _) in ((st1_s, st1_d), (st2_s, st2_d)):
         assert float(((s_s - s_d).abs() / s_d.abs().clamp_min(1e-30)).max()) <= 1e-13 and float(((q_s - q_d).abs() / q_d.abs().clamp_min(1e-30)).max()) <= 1e-13
     assert bool(torch.isfinite(y2_s).all()) and float(y2_s.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ polyphase decoder convolutions
+@pytest.mark.parametrize("C0,C1,Cout,dims,B", [(32, 64, 32, (16, 16, 16), 1), (64, 128, 64, (8, 16, 8), 2), (128, 256, 128, (8, 8, 8), 1),
+                                               (32, 64, 32, (64, 64, 64), 2), (16, 32, 64, (4, 6, 10), 1)])
+@pytest.mark.parametrize("mode", [4, 2])
+def test_polyphase_upsampled_conv_equals_literal_form(C0, C1, Cout, dims, B, mode):
+    """SingleConv on cat((skip, upsample_nearest(x))) (components/unet3d.py:291,330): the polyphase form (upsampled channels as a
+    2x2x2-tap convolution per output parity class on the coarse volume, merged weights, added in the fine launch's epilogue) against the
+    literal form (src1 read at half resolution in the halo stage) and against torch in fp64.  Exact algebra, another rounding order:
+    both must be fp32-class; the (64^3, B=2) case runs the tap-masked 128-wide kernel for the coarse launch."""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(C0 + C1 + dims[0])
+    D, H, W = dims
+    x0 = torch.randn(B, C0, D, H, W, generator=g)
+    x1 = torch.randn(B, C1, D // 2, H // 2, W // 2, generator=g) * 1.5 + 0.2
+    conv = SingleConv(C0 + C1, Cout)
+    conv.load_state_dict({k: S.synthetic_tensor("p." + k, tuple(v.shape), 2) for k, v in conv.state_dict().items()})
+    up = F.interpolate(x1.double(), size=(D, H, W), mode="nearest")
+    cat = torch.cat((x0.double(), up), dim=1)
+    ref = F.relu(F.conv3d(F.group_norm(cat, conv.groupnorm.num_groups, conv.groupnorm.weight.double(), conv.groupnorm.bias.double(), eps=1e-5),
+                          conv.conv.weight.double(), None, padding=1))
+    conv = conv.to(DEV)
+    s0 = x0.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    s1 = x1.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    outs = {}
+    try:
+        saved = (ops.CONV_MODE, ops.POLYPHASE_UPCONV)
+        ops.CONV_MODE = mode
+        for poly in (True, False):
+            ops.POLYPHASE_UPCONV = poly
+            y, (s_, q_, V) = conv.run(s0, s1)
+            outs[poly] = (y.permute(0, 4, 1, 2, 3).cpu().double(), s_.cpu(), q_.cpu(), ops._lib.load().gn_last_kernel().decode())
+    finally:
+        ops.CONV_MODE, ops.POLYPHASE_UPCONV = saved
+    scale = float(ref.abs().max())
+    e_poly, e_lit = float((outs[True][0] - ref).abs().max()), float((outs[False][0] - ref).abs().max())
+    print(f"{C0}+{C1}->{Cout} {dims} mode {mode}: err vs fp64 polyphase {e_poly:.2e} / literal {e_lit:.2e} (max |y| {scale:.2f}); main kernel {outs[True][3]}")
+    tol = 2e-5 if mode == 4 else 3e-4
+    assert e_poly <= tol * max(1.0, scale) and e_poly <= 2 * max(e_lit, 2e-6)
+    # the epilogue statistics are those of the final values in both forms
+    for i in (1, 2):
+        assert float((outs[True][i] - outs[False][i]).abs().max()) <= 1e-3 * max(1.0, float(outs[False][i].abs().max())) * (1e-2 if mode == 4 else 1.0)

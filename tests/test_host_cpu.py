@@ -284,3 +284,20 @@ def test_prediction_zarr_is_readable_by_an_independent_zarr_v2_reader(tmp_path):
     a = rng.normal(size=(10, 7)).astype(np.float64)
     g.array("a", a, chunks=(4, 3), compressor=("zlib", 1))
     assert np.array_equal(_independent_zarr_v2_read(str(tmp_path / "chunked.zarr"), "a"), a)
+
+
+def test_polyphase_weights_algebra():
+    """ops.polyphase_weights on the host: conv(cat(skip, up(x))) == conv(skip; w0) + interleave(conv_coarse(x; wm)) in fp64 torch"""
+    g = torch.Generator().manual_seed(0)
+    C0, C1, Cout, D = 3, 5, 32, 6
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3, generator=g, dtype=torch.float64)
+    x0 = torch.randn(1, C0, D, D, D, generator=g, dtype=torch.float64)
+    x1 = torch.randn(1, C1, D // 2, D // 2, D // 2, generator=g, dtype=torch.float64)
+    w0, wm, mask = ops.polyphase_weights(w, C0)
+    want = torch.nn.functional.conv3d(torch.cat((x0, torch.nn.functional.interpolate(x1, scale_factor=2, mode="nearest")), dim=1), w, None, padding=1)
+    part = torch.nn.functional.conv3d(x1, wm.double(), None, padding=1).reshape(1, 2, 2, 2, Cout, D // 2, D // 2, D // 2)       # [pz][py][px][n][i][j][k]
+    fine = part.permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(1, Cout, D, D, D)                                     # z = 2 i + pz ...
+    got = torch.nn.functional.conv3d(x0, w0.double(), None, padding=1) + fine
+    assert float((got - want).abs().max()) <= 1e-5                                                            # (w0 / wm are stored in fp32)
+    assert int((wm != 0).reshape(8 * Cout, -1, 27).any(dim=1).sum(dim=1).max()) == 8                         # 2 x 2 x 2 taps per class
+    assert all(bin(int(m) & 0xFF).count("1") in (1, 2, 4, 8) for m in mask.tolist())
