@@ -35,7 +35,8 @@ PROTOTYPES = {
     "gn_channel_stats": [_vp, _i32, _i64, _i32, _vp, _vp, _vp],
     "gn_groupnorm_affine": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "gn_conv3d_gcr": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
-    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "gn_upconv_partial": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_grid_tile_flags": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_stats": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp],

@@ -80,19 +80,17 @@ class SingleConv(PackedModule, nn.Sequential):
                 kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
                 sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
                 sparse["small_out"] = small_out
-            if (src1 is not None and ops.POLYPHASE_UPCONV and mode != ops.SPLIT_BF16X3 and (8 * cout) % 128 == 0 and 8 * cout <= 1024
-                    and src1.shape[-1] <= 384):
+            if src1 is not None and ops.POLYPHASE_UPCONV and mode != ops.SPLIT_BF16X3 and src1.shape[-1] <= 384:
                 # polyphase form: the nearest-upsampled channels as a 2x2x2-tap convolution per output parity class on the COARSE volume
-                # (8/27 of their MACs, staged once per coarse voxel instead of once per fine voxel), added in the fine launch's epilogue
+                # (8/27 of their MACs, the coarse halo staged once for all classes: csrc/upconv.hip), added in the fine launch's epilogue
                 c0 = src0.shape[-1]
                 pkey = ("poly",) + key + (c0,)
                 if pkey not in cache:
-                    w0, wm, mask = ops.polyphase_weights(self.conv.weight, c0)
+                    w0, wm, _ = ops.polyphase_weights(self.conv.weight, c0)
                     dev = self.conv.weight.device
-                    cache[pkey] = (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_conv_weight_split(wm, mode).to(dev), mask.to(dev))
-                pk0, pkm, mask = cache[pkey]
-                part = ops.conv3d_gcr_split(src1, None, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, 8 * cout, relu=False, act_inv=act_inv,
-                                            tapmask=mask)
+                    cache[pkey] = (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_upconv_weight(wm, cout, mode).to(dev))
+                pk0, pkm = cache[pkey]
+                part = ops.upconv_partial(src1, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, cout, act_inv=act_inv)
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)
                 return r if with_stats else (r, None)

@@ -59,11 +59,9 @@ struct SplitArgs {
     const unsigned char *tile_active;
     const float *kconst;
     // polyphase form of a layer whose second source is nearest-upsampled (the decoders' first convolutions): the upsampled part is a
-    // 2x2x2-tap convolution per output parity class on the COARSE volume (8/27 of the MACs), computed by a separate launch over the coarse
-    // source with N' = 8 * Cout class-blocked output channels and merged weights; tapmask[tap] bit i = 32-wide column block i has non-zero
-    // weights at this tap (the 128-wide variant skips the other MFMAs); the fine launch over the first source then adds
-    // partial[b][z>>1][y>>1][x>>1][((z&1)*4 + (y&1)*2 + (x&1)) * Cout + n] before the ReLU.
-    const unsigned *tapmask;
+    // 2x2x2-tap convolution per output parity class on the COARSE volume (8/27 of the MACs), computed by gn_upconv_partial (upconv.hip);
+    // the launch over the full-resolution source then adds partial[b][z>>1][y>>1][x>>1][((z&1)*4 + (y&1)*2 + (x&1)) * Cout + n] before
+    // the ReLU.
     const float *partial;
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
@@ -437,10 +435,9 @@ typedef float f32x4w __attribute__((ext_vector_type(4)));
 #ifndef SPW_PIPE
 #define SPW_PIPE 0
 #endif
-template <int P, bool F16, bool ZTWIN, bool MASKED = false>
+template <int P, bool F16, bool ZTWIN>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
     static_assert(P == 2, "the wide variant is sized for the two-plane modes");
-    static_assert(!(ZTWIN && MASKED), "the tap mask belongs to the 128-wide form");
     constexpr bool PIPE = SPW_PIPE != 0, TWOLEVEL = !PIPE;
     constexpr int NT = ZTWIN ? 1 : 2;
     constexpr int TZ = ZTWIN ? 2 * SP_TZ : SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
@@ -625,14 +622,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             }
             if (tap == 0) issue_rows(sn);                                        // always (uniform wait counts); unused after the last slice
             __builtin_amdgcn_sched_barrier(0);
-            // MASKED (class-blocked polyphase weights): only the column blocks with non-zero weights at this tap are multiplied
-            const unsigned tm = MASKED ? (p.tapmask[tap] >> (cb * 4 + cg * 2)) & 3u : 3u;
 #define SPW_PROD(IA, IB)                                                                                                       \
             _Pragma("unroll") for (int u = 0; u < NT; ++u) {                                                                   \
-                if (!MASKED || ((tm >> u) & 1u)) {                                                                             \
-                    acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                     \
-                    acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                     \
-                }                                                                                                              \
+                acc[0][u] = mfma16<F16>(a0[IA], bf[u][IB], acc[0][u]);                                                         \
+                acc[1][u] = mfma16<F16>(a1[IA], bf[u][IB], acc[1][u]);                                                         \
             }
             SPW_PROD(1, 0)
             if (tap >= 8 && tap < 8 + NIT && s + 1 < nslices) convert_row(tap - 8, sn, (s + 1) & 1);
@@ -735,7 +728,7 @@ static bool gn_ztwin_enabled() {
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
                                    int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                                   const float *kconst, int kreach, const unsigned *tapmask, const float *partial, void *stream) {
+                                   const float *kconst, int kreach, const float *partial, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -751,9 +744,8 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
-    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach; p.tapmask = tapmask; p.partial = partial;
+    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach; p.partial = partial;
     GN_REQUIRE(!partial || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: a polyphase partial needs even dims");
-    GN_REQUIRE(!(tapmask && tile_active), "gn_conv3d_gcr_split: tapmask and tile_active are exclusive");
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
@@ -778,11 +770,7 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
     const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
     const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
-    if (wide128 && tapmask && Cout <= 1024) {   // (the mask is a hint: every other variant multiplies the zero blocks too)
-        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false, true>" : "conv3d_split_wide_kernel<2, false, false, true>");
-    } else if (wide128) {
+    if (wide128) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false>" : "conv3d_split_wide_kernel<2, false, false>");

@@ -365,7 +365,8 @@ def grid_tile_flags(flat_idx, B, grid_shape, reach=1):
 SPARSE_FIRST_CONV = os.environ.get("GARMENTNETS_SPARSE_CONV", "1") != "0"
 
 
-# polyphase form of the decoders' first convolutions (nearest-upsampled second source): "0" = literal form (src1 read at half resolution)
+# polyphase form of the decoders' first convolutions (nearest-upsampled second source: 8/27 of those channels' MACs, csrc/upconv.hip);
+# "0" = literal form (src1 read at half resolution in the halo stage).  Measured: 163.8 vs 165.8 ms per 16-garment step.
 POLYPHASE_UPCONV = os.environ.get("GARMENTNETS_POLYPHASE", "1") != "0"
 
 
@@ -375,7 +376,8 @@ def polyphase_weights(w, c0):
      wm (8 * Cout, C1, 3,3,3): the upsampled part as a convolution over the COARSE volume, output channel (class, n), class = 4 pz + 2 py + px
          the parity of the fine output voxel: a fine tap d in {-1, 0, +1} of an even voxel lands on coarse offset {-1, 0, 0}, of an odd voxel
          on {0, 0, +1}, so the 27 fine taps merge (sums of weights, fp64) into 2 x 2 x 2 coarse taps per class -- exact algebra;
-     tapmask int32 [27]: bit i = 32-wide output block i of wm has a non-zero weight at tap (kd * 3 + kh) * 3 + kw)."""
+     tapmask int32 [27]: bit i = 32-wide output block i of wm has a non-zero weight at tap (kd * 3 + kh) * 3 + kw -- diagnostic: every
+         class uses exactly 2 x 2 x 2 of the 27 coarse taps)."""
     w = w.detach().double().cpu()
     cout = w.shape[0]
     w0, w1 = w[:, :c0].float(), w[:, c0:]
@@ -391,14 +393,52 @@ def polyphase_weights(w, c0):
     return w0.contiguous(), wm.contiguous(), mask.to(torch.int32)
 
 
+def pack_upconv_weight(wm, cout, mode):
+    """merged polyphase weights wm (8 * cout, C1, 3,3,3) of polyphase_weights -> SplitPack for gn_upconv_partial: the 8 taps class
+    (pz, py, px) uses are wm[..., pz + iz, py + iy, px + ix], i in {0,1}; fragment order [C1/16][tap = 4 iz + 2 iy + ix][class][cout/32]
+    [plane][h][r][8] (lane 32 h + r holds channels 8h..8h+7 of output r of the block), per-row power-of-two scale for fp16 planes."""
+    if mode not in (SPLIT_BF16X2, SPLIT_F16X2):
+        raise ValueError("gn_upconv_partial runs the two-plane modes only")
+    wm = wm.detach().float().cpu()
+    c1 = wm.shape[1]
+    assert wm.shape[0] == 8 * cout and c1 % 16 == 0 and cout % 32 == 0
+    taps = torch.empty((8, 8, cout, c1), dtype=torch.float32)                                     # [class][tap][n][k]
+    for c in range(8):
+        pz, py, px = c >> 2, (c >> 1) & 1, c & 1
+        for t in range(8):
+            iz, iy, ix = t >> 2, (t >> 1) & 1, t & 1
+            taps[c, t] = wm[c * cout:(c + 1) * cout, :, pz + iz, py + iy, px + ix]
+    scale = torch.ones(8, cout)
+    if mode == SPLIT_F16X2:
+        m = taps.abs().amax(dim=(1, 3))
+        ok = torch.isfinite(m) & (m > 0)
+        scale = torch.where(ok, torch.exp2(-torch.floor(torch.log2(torch.where(ok, m, torch.ones_like(m))))), scale)
+    dt = torch.float16 if mode == SPLIT_F16X2 else torch.bfloat16
+    t_ = (taps * scale[:, None, :, None]).reshape(8, 8, cout // 32, 32, c1 // 16, 2, 8)            # [class][tap][blk][r][S][h][i]
+    t_ = t_.permute(4, 1, 0, 2, 5, 3, 6)                                                          # [S][tap][class][blk][h][r][i]
+    p1 = t_.to(dt)
+    p2 = (t_ - p1.float()).to(dt)
+    pk = torch.stack((p1, p2), dim=4).contiguous()                                                # [S][tap][class][blk][plane][h][r][i]
+    return SplitPack(pk.view(torch.int16).reshape(-1), mode, (1.0 / scale).reshape(-1).contiguous())
+
+
+def upconv_partial(src1, a1, d1, pack, cout, act_inv=None):
+    """coarse source [B][Dc][Hc][Wc][C1] -> polyphase partial sums [B][Dc][Hc][Wc][8 * cout] (csrc/upconv.hip)"""
+    B, Dc, Hc, Wc, C1 = src1.shape
+    part = torch.empty((B, Dc, Hc, Wc, 8 * cout), dtype=torch.float32, device=src1.device)
+    _lib.call("gn_upconv_partial", _p(src1), C1, _p(_chk(a1, torch.float32, "a")), _p(_chk(d1, torch.float32, "d")), _p(pack.tensor), pack.mode,
+              _p(pack.out_scale), _p(act_inv), B, Dc, Hc, Wc, cout, _p(part), _stream())
+    return part
+
+
 def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1,
-                     tapmask=None, partial=None):
+                     partial=None):
     B, D, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
     _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
-              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(tapmask), _p(partial), _stream())
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

@@ -194,17 +194,23 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
  * takes them from dense launches of the same layers over a 5 x 5 x 5 all-zero volume with the same affines) and are stored without
  * touching the matrix cores.  kreach = 1: the layer fed by the scattered volume; 2: the layer behind it.  The output is bit-identical
  * to the dense launch.  Two-plane modes only; the launch pins the kernel variant (128-wide for Cout % 128 == 0, else the 32-wide one). */
-/* Polyphase form for a nearest-upsampled second source (torch.cat((skip, upsample(x))) -> Conv3d, components/unet3d.py:291,330): the
- * upsampled channels contribute, per output parity class, a 2x2x2-tap convolution over the COARSE volume (8/27 of the MACs).
- * garmentnets_amd launches (1) this function over the coarse source alone with merged, class-blocked weights (Cout' = 8 * Cout,
- * relu = 0; tapmask [27] words: bit i = 32-wide output block i is non-zero at that tap -- a hint the 128-wide variant uses to skip
- * MFMAs) into a partial buffer [B][D/2][H/2][W/2][8 * Cout], then (2) over the full-resolution source alone with `partial` set: the
- * epilogue adds partial[b][z>>1][y>>1][x>>1][((z&1)*4 + (y&1)*2 + (x&1)) * Cout + n] before the ReLU.  tapmask / partial NULL = the
- * literal form (src1 read at half resolution in the halo stage). */
+/* `partial` (NULL, or [B][D/2][H/2][W/2][8][Cout] from gn_upconv_partial): the polyphase form of a layer whose second source is
+ * nearest-upsampled -- this launch then covers the full-resolution source alone (src1 NULL) and its epilogue adds
+ * partial[b][z>>1][y>>1][x>>1][(z&1)*4 + (y&1)*2 + (x&1)][n] before the ReLU. */
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                         const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H, int W,
                         int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                        const float *kconst, int kreach, const unsigned *tapmask, const float *partial, void *stream);
+                        const float *kconst, int kreach, const float *partial, void *stream);
+
+/* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
+ * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27
+ * fine taps merge into 8 coarse taps per output parity class (sums of weights, host side, fp64) -- 8/27 of the MACs of those channels,
+ * and the coarse halo is staged once for all classes instead of once per fine voxel.  src1 [B][Dc][Hc][Wc][C1]; a, d [B][C1]: the
+ * GroupNorm affine of THESE channels (contiguous slices of gn_groupnorm_affine's result); wp: merged weights in fragment order
+ * [C1/16][8 taps][8 classes][Cout/32][2 planes][64 lanes] x 16 B with out_scale [8 * Cout] (garmentnets_amd.ops.pack_upconv_weight);
+ * partial [B][Dc][Hc][Wc][8 * Cout] in true units, no activation.  Arithmetic: the two-plane split of gn_conv3d_gcr_split. */
+int gn_upconv_partial(const float *src1, int C1, const float *a, const float *d, const void *wp, int mode, const float *out_scale,
+                      const float *act_inv_scale, int B, int Dc, int Hc, int Wc, int Cout, float *partial, void *stream);
 
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */

@@ -1007,7 +1007,7 @@ def test_polyphase_upsampled_conv_equals_literal_form(C0, C1, Cout, dims, B, mod
     """SingleConv on cat((skip, upsample_nearest(x))) (components/unet3d.py:291,330): the polyphase form (upsampled channels as a
     2x2x2-tap convolution per output parity class on the coarse volume, merged weights, added in the fine launch's epilogue) against the
     literal form (src1 read at half resolution in the halo stage) and against torch in fp64.  Exact algebra, another rounding order:
-    both must be fp32-class; the (64^3, B=2) case runs the tap-masked 128-wide kernel for the coarse launch."""
+    both must be fp32-class (csrc/upconv.hip: one wave per parity class, the coarse halo staged once for all eight)."""
     from garmentnets_amd.components.unet3d import SingleConv
     g = torch.Generator().manual_seed(C0 + C1 + dims[0])
     D, H, W = dims
