@@ -111,8 +111,14 @@ class KernelTimer:
             vox = float(B) * D * H * W
             return _lib.load().gn_last_kernel().decode(), 54.0 * cin * cout * vox, (cin + cout) * 4.0 * vox + wbytes
 
+        def describe_up(res_, src1, a1, d1, pack, cout, **kw):       # polyphase partial: 8 coarse taps x 8 parity classes per coarse voxel
+            B, Dc, Hc, Wc, C1 = src1.shape
+            vox = float(B) * Dc * Hc * Wc
+            return "upconv_partial_kernel", 2.0 * 64 * C1 * cout * vox, (C1 + 8 * cout) * 4.0 * vox + pack.tensor.numel() * 2.0
+
         ops.conv3d_gcr = self._wrap(ops.conv3d_gcr, describe)
         ops.conv3d_gcr_split = self._wrap(ops.conv3d_gcr_split, describe)
+        ops.upconv_partial = self._wrap(ops.upconv_partial, describe_up)
 
     def install_points(self):
         """PointNet++ operators (config[1]): work = squared-distance evaluations for fps / ball query / kNN, FLOPs for the GEMMs"""
