@@ -109,6 +109,34 @@ __device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Epilogue of one 32 x 32 D fragment when the tile lies inside the volume and is active: lane (h, r) holds channel n and the 16 voxels
+// (y = j, x = 4 h + k), q = 4 j + k, of one y half.  `ob` / `pb` point at (j, k) = (0, 0) of this lane; every other (j, k) is a
+// workgroup-uniform element offset from there (the generic path below spent ~40 instructions per value, five of them quarter-rate
+// integer multiplies, on 64-bit addresses and bounds: 9 % of the 128 -> 128 layer, 25 % of a 32 -> 32 one).  Same arithmetic, same
+// order as the generic path: value * scale (+ polyphase partial) (ReLU), channel statistics accumulated q = 0 .. 15.
+__device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32x16s &val, float osc, float *ob, const float *pb, float &ssum, float &ssq) {
+    const int64_t rs = (int64_t)p.W * p.Cout;
+    float pv[16];
+    if (pb) {
+        const int64_t prs = (int64_t)(p.W >> 1) * 8 * p.Cout;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = q >> 2, k = q & 3;
+            pv[q] = pb[(j >> 1) * prs + (int64_t)((k >> 1) * 8 + (j & 1) * 2 + (k & 1)) * p.Cout];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = q >> 2, k = q & 3;
+        float v = __fmul_rn(val[q], osc);
+        if (pb) v = __fadd_rn(v, pv[q]);
+        if (p.relu) v = gn_relu(v);
+        ob[j * rs + (int64_t)k * p.Cout] = v;
+        ssum += v;
+        ssq = fmaf(v, v, ssq);
+    }
+}
+
 // LDS halo layout.  ds_read_b128 is serviced in four 16-lane groups that are NOT contiguous lane ranges ({0-3,12-15,20-27},
 // {4-11,16-19,28-31} and the same +32: MI355X_MICROARCH.md, LDS table); with the fragment's row r = (y = r>>3, x = r&7) a group is
 // four runs of 4 x-consecutive voxels in 4 different halo rows, and 16-byte bank quads repeat every 256 B.  Two planes (P = 2):
@@ -370,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+    const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -377,6 +406,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
             const int t = f & 1, gz = z0 + wave + 4 * (f >> 1);
             const int n = n0 + u * 32 + r;
             const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+            if (full) {
+                const int gy = y0 + t * 4, gx = x0 + 4 * h;
+                float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n;
+                const float *pb = p.partial ? p.partial + ((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((gz & 1) * 4 * p.Cout + n) : nullptr;
+                sp_store_frag_full(p, tot[f][u], osc, ob, pb, ssum[u], ssq[u]);
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -499,31 +535,55 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     const int c4 = (tid & 3) * 4;                   // 512 % 4 == 0: the same channel quad every iteration
     f32x4w raw[NIT];
     unsigned inb = 0;                               // bit it: the voxel of iteration it lies inside the volume
+    // rows of the full-resolution source: the byte offset of (voxel, channel quad) inside this sample fits 32 bits (checked on the host
+    // side of the launch: D*H*W*C0*4 < 2^32), so a row costs ONE register across the MFMA loop and one add per slice
+    // (global_load saddr form: 64-bit scalar base + 32-bit vector offset); rows outside the volume read offset 0 and are masked later
+    unsigned voff[NIT], inb0 = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 512;
+        const int hv = (idx < HVOX * 4 ? idx : HVOX * 4 - 1) >> 2;
+        const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool in = idx < HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        voff[it] = in ? ((unsigned)((gz * p.H + gy) * p.W + gx) * (unsigned)p.C0 + (unsigned)c4) * 4u : (unsigned)c4 * 4u;
+        if (in) inb0 |= 1u << it;
+    }
+    const float *const base0 = p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0;
     auto issue_rows = [&](int sl) {
         const int c0 = sl * SP_KS;
-        const bool from1 = c0 >= p.C0;
-        const float *src = from1 ? p.src1 : p.src0;
-        const int Cs = from1 ? p.C1 : p.C0;
-        const int cs = from1 ? c0 - p.C0 : c0;
+        if (c0 < p.C0) {
+            inb = inb0;
+            const unsigned cb4 = (unsigned)c0 * 4u;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[it]) : "v"(voff[it] + cb4), "s"(base0) : "memory");
+            return;
+        }
+        // the half-resolution (nearest-upsampled) source: only reached with ops.POLYPHASE_UPCONV off; offsets re-derived per slice
+        const int cs = c0 - p.C0;
         inb = 0;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 512;
+            const int idx = tl + it * 512;
             const int hv = (idx < HVOX * 4 ? idx : HVOX * 4 - 1) >> 2;
             const int hx = hv % SP_HX, hy = (hv / SP_HX) % SP_HY, hz = hv / (SP_HX * SP_HY);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool in = idx < HVOX * 4 && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            int64_t off = (int64_t)b * (from1 ? (int64_t)D1 * H1 * W1 : (int64_t)p.D * p.H * p.W) * Cs;   // a valid address when outside
+            int64_t off = (int64_t)b * D1 * H1 * W1 * p.C1;                      // a valid address when outside
             if (in) {
-                if (from1) off = ((((int64_t)b * D1 + (gz >> 1)) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * Cs + cs + c4;
-                else off = ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * Cs + cs + c4;
+                off = ((((int64_t)b * D1 + (gz >> 1)) * H1 + (gy >> 1)) * W1 + (gx >> 1)) * p.C1 + cs + c4;
                 inb |= 1u << it;
             }
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[it]) : "v"(src + off) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[it]) : "v"(p.src1 + off) : "memory");
         }
     };
     auto convert_row = [&](int it, int sl, int buf) {
-        const int idx = tid + it * 512;
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                // (as above: the halo address of the row is recomputed, not kept)
+        const int idx = tl + it * 512;
         asm volatile("" : "+v"(raw[it]));           // the loads above are invisible to hipcc's waitcnt pass: pin the first use here
         if (idx < HVOX * 4) {
             const int hv = idx >> 2;
@@ -657,12 +717,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+    const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int n = n0 + u * 32 + r;
             const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+            if (full) {
+                const int gy = y0 + t * 4, gx = x0 + 4 * h;
+                float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n;
+                const float *pb = p.partial ? p.partial + ((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((gz & 1) * 4 * p.Cout + n) : nullptr;
+                sp_store_frag_full(p, TWOLEVEL ? tot[t][u] : acc[t][u], osc, ob, pb, ssum[u], ssq[u]);
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -763,13 +831,16 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
     // an occupancy-aware launch pins the kernel variant (so that the border-class constants, taken from a launch over a tiny volume, come
     // out of the same instruction stream): the 128-wide variant when Cout % 128 == 0, conv3d_split_kernel<1> otherwise
-    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && ((int64_t)tiles * (Cout / 128) * B >= 512 || tile_active);
+    // (its row loads address one sample of the full-resolution source with 32-bit byte offsets)
+    const bool fits32 = (int64_t)D * H * W * C0 * 4 < ((int64_t)1 << 32);
+    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && fits32 && ((int64_t)tiles * (Cout / 128) * B >= 512 || tile_active);
+    GN_REQUIRE(!tile_active || fits32, "gn_conv3d_gcr_split: the occupancy-aware launch needs D*H*W*C0*4 < 2^32 bytes per sample");
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
     // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
     const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
-    const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
+    const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && fits32 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
     if (wide128) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);

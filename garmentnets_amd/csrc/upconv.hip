@@ -225,6 +225,14 @@ __global__ __launch_bounds__(512, 1) void upconv_partial_kernel(UpArgs p) {
             const int t = f & 1, gz = z0 + (f >> 1);
             const int n = cls * p.Cout + (cb * NT + u) * 32 + r;
             const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+            if (z0 + TZC <= p.Dc && y0 + 8 <= p.Hc && x0 + 8 <= p.Wc) {       // tile inside the volume (workgroup-uniform): one 64-bit
+                                                                              // address per fragment, uniform offsets for its 16 voxels
+                float *ob = p.partial + ((((int64_t)b * p.Dc + gz) * p.Hc + (y0 + t * 4)) * p.Wc + (x0 + 4 * h)) * pc + n;
+                const int64_t rs = (int64_t)p.Wc * pc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ob[(q >> 2) * rs + (q & 3) * pc] = __fmul_rn(tot[f][u][q], osc);
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
