@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
     }
     // ---- epilogue: ReLU, coalesced stores, optional statistics of the output
     const int gz = z0 + wave;
+    const bool full = z0 + CV_TZ <= p.D && y0 + CV_TY <= p.H && x0 + CV_TX <= p.W;    // tile inside the volume (workgroup-uniform)
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
@@ -306,6 +307,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int n = n0 + u * 32 + r;
+            if (full) {                              // one 64-bit address per fragment, workgroup-uniform offsets for its 16 voxels (q = 4 j + k:
+                                                     // y = j, x = 4 h + k) -- the generic path costs ~40 instructions per value
+                float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + (y0 + t * 4)) * p.W + (x0 + 4 * h)) * p.Cout + n;
+                const int64_t rs = (int64_t)p.W * p.Cout;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float v = tot[t][u][q];
+                    if (p.relu) v = gn_relu(v);
+                    ob[(q >> 2) * rs + (int64_t)(q & 3) * p.Cout] = v;
+                    ssum[u] += v;
+                    ssq[u] = fmaf(v, v, ssq[u]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int i = (q & 3) + 8 * (q >> 2) + 4 * h;
