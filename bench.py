@@ -67,6 +67,11 @@ def parse():
                     help="arithmetic of the 3x3x3 convs of the HEADLINE pass: f16x2 (default; fp32 operands split into two fp16 planes, fp32 "
                          "accumulation), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (preview quality)")
     ap.add_argument("--decode-mode", default="f16x2", choices=["f16x2", "fp32"], help="arithmetic of the decoder MLPs of the headline pass")
+    ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
+                    help="1 (default): one batch at a time (predict.predict_batch, the reference's loop); 2: every timed pass keeps two batches in "
+                         "flight -- batch k+1's dense path is queued before batch k's host-synchronising tail is finished (predict.PredictJob).  "
+                         "Either way a timed pass begins and finishes all its K batches")
+    ap.add_argument("--no-in-flight-pass", action="store_true", help="skip the extra timed pass with two batches in flight (reported as two_in_flight)")
     ap.add_argument("--no-strict-pass", action="store_true", help="skip the second timed pass in strict fp32 arithmetic")
     ap.add_argument("--no-host-io-pass", action="store_true", help="skip the timed pass that includes H2D of the clouds / D2H of the meshes")
     ap.add_argument("--no-occupancy-pass", action="store_true", help="skip the timed passes with the occupancy-aware first convolution")
@@ -318,7 +323,7 @@ def main():
     from garmentnets_amd import ops, synthetic as S
     from garmentnets_amd.batch import Batch
     from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
-    from garmentnets_amd.predict import predict_batch, to_host
+    from garmentnets_amd.predict import PredictJob, predict_batch, to_host
 
     hp = S.default_hparams(grid=args.grid, reduce_method=args.reduce)
     sd = S.synthetic_state_dict(hp, 0)
@@ -353,17 +358,37 @@ def main():
             return {k: v.cpu() for k, v in res.items() if torch.is_tensor(v)}
         return [to_host(r) for r in res]
 
+    pipelined = [False]                              # set below: --pipeline-depth 2, full workload, fixed iso level
+
+    def run_steps(fn, n):
+        """n steps of fn; with the pipeline on, the same n batches through predict.PredictJob: batch k+1's dense path is queued before
+        batch k's host-synchronising tail (vertex counts, mesh slices, surface decode; on a stream of its own) is finished -- every batch
+        is begun AND finished inside the call"""
+        res = None
+        if not (pipelined[0] and fn in (step, step_host_io)):
+            for _ in range(n):
+                res = fn()
+            return res
+        prev = None
+        for k in range(n):
+            d = host_data.to(dev, non_blocking=True) if fn is step_host_io else data
+            job = PredictJob(model, d, args.volume_size, 0.5, 0.5, "ascent", bank=1 + (k & 1))
+            if prev is not None:
+                res = prev.finish(host=fn is step_host_io)
+            prev = job
+        if prev is not None:
+            res = prev.finish(host=fn is step_host_io)
+        return res
+
     def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
+        run_steps(fn, warmup)
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
         timer.reset()
         timer.enabled = True
         t0 = time.perf_counter()
-        for _ in range(steps):
-            res = fn()
+        res = run_steps(fn, steps)
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
@@ -383,7 +408,16 @@ def main():
         if any(bool(torch.isnan(r["verts"]).any()) for r in probe):
             auto_level[0] = True
         del probe
-    dt, res, groups = timed(step, args.steps, max(0, args.warmup - (1 if args.workload == "full" else 0)))
+    pipelined[0] = args.workload == "full" and args.pipeline_depth == 2 and not auto_level[0]
+    dt, res, groups = timed(step, args.steps, max(2, args.warmup - 1) if pipelined[0] else max(0, args.warmup - (1 if args.workload == "full" else 0)))
+    in_flight = None
+    if args.workload == "full" and not pipelined[0] and not auto_level[0] and not args.no_in_flight_pass:
+        # the same K batches with two in flight (predict.PredictJob); warm-up 2: the second batch's buffers have to exist in the allocator
+        pipelined[0] = True
+        dt_q, res_q, _ = timed(step, args.steps, 2)
+        del res_q
+        in_flight = dt_q
+        pipelined[0] = False
     verts_total = None
     if args.workload == "full":
         verts_total = sum(int(r["verts"].shape[0]) for r in res)
@@ -469,7 +503,7 @@ def main():
     n_local = (hi - lo) * args.steps
     occ_t = [occupancy[k].get(f, 0.0) for k, f in (("synthetic_clouds", "seconds"), ("realistic_occupancy", "seconds"), ("realistic_occupancy", "seconds_dense"))] \
         if occupancy else [0.0, 0.0, 0.0]
-    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0] + occ_t, device=metrics_dev)
+    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0] + occ_t + [in_flight or 0.0], device=metrics_dev)
     if rank == 0:
         value, tmax = parallel.aggregate_throughput(per_rank)
         garments = sum(r[0] for r in per_rank)
@@ -498,11 +532,22 @@ def main():
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level[0] else 0.5,
                        "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
-            "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh)",
+            "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh); K batches "
+                            "begun and finished between the two barriers" + (
+                                ", two in flight: batch k+1's PointNet++/UNet/lattice is queued before batch k's tail (vertex counts to the host, mesh "
+                                "slices, surface decode) is finished (predict.PredictJob; bit-equal results: tests/test_gpu_api.py)" if pipelined[0] else ", one at a time"),
+            "pipeline_depth": 2 if pipelined[0] else 1,
             "rccl_ranks_seen": len(per_rank),
             "stages_ms": stages_ms,
             "roofline": roofline,
         }
+        if in_flight is not None:
+            tq = max(r[7] for r in per_rank)
+            line["two_in_flight"] = {"value": garments / tq, "unit": "garments/s", "ms_per_step": 1e3 * tq / args.steps, "steps": args.steps,
+                                     "what": "the same K batches through predict.PredictJob: batch k+1's PointNet++ / UNet / lattice is queued before batch "
+                                             "k's tail (vertex counts to the host, mesh slices, surface decode; on its own stream) is finished.  Bit-equal "
+                                             "results (tests/test_gpu_api.py); the step is matrix-core / power bound, so hiding the latency-bound tail buys "
+                                             "little"}
         if strict:
             ts = max(r[2] for r in per_rank)
             line["strict_fp32"] = {"value": garments / ts, "unit": "garments/s", "ms_per_step": 1e3 * ts / args.steps, "steps": args.steps,

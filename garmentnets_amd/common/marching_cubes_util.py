@@ -120,13 +120,14 @@ class IsoBatchJob:
     queues the per-garment tails (slicing, vertex look-ups).  predict_batch enqueues the first half of the batch, decodes the second
     half's lattice meanwhile, then enqueues that."""
 
-    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
+    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent", bank=0):
         if gradient_direction not in ("ascent", "descent"):
             raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % gradient_direction)
         self.Q, self.level, self.sigma, self.direction = int(Q), float(iso_surface_level), float(sigma), gradient_direction
         self.cap_v = max(4096, int(6 * self.Q ** 2))
         self.cap_f = 2 * self.cap_v + 64
         self.vols, self.ggms, self.mcs, self.recs, self.lanes_used = [], [], [], [], []
+        self.bank = int(bank)                        # a second set of slot buffers for a caller that keeps two batches in flight (predict.PredictJob)
 
     def enqueue(self, wnf_part):
         B0, Bp = len(self.vols), wnf_part.shape[0]
@@ -145,7 +146,7 @@ class IsoBatchJob:
             vol = wnf_part[i].float().contiguous()
             self.vols.append(vol)
             if USE_ISO_GRAPHS:                                         # results live in slot b's static buffers until its next replay
-                key = (b, self.Q, self.level, self.sigma, self.cap_v, str(vol.device))
+                key = (b, self.Q, self.level, self.sigma, self.cap_v, str(vol.device), self.bank)
                 if key not in _ISO_GRAPHS:
                     if len(_ISO_GRAPHS) >= 256:
                         _ISO_GRAPHS.clear()

@@ -66,45 +66,61 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
     return results
 
 
-def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
-    """-> (results, device bool: the WNF holds a NaN); stop_on_nan: -> (None, True) before the per-garment tail when it does"""
+def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, iso_bank=0):
+    """everything that needs no host synchronisation, queued on the current stream: PointNet++ -> gridding + UNet -> WNF lattice ->
+    (fixed level) the per-garment GGM / MC33 slot graphs on the iso side streams -> the batch's grip-point post-processing.
+    -> state dict for _tail_phase"""
     with torch.no_grad():
         pointnet2_result = model.pointnet2_forward(batch)
         unet3d_result = model.unet3d_forward(pointnet2_result)
         nocs_data = pointnet2_result["nocs_data"]
         B = nocs_data.num_graphs
-        # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first).  The
-        # lattice is decoded in two halves: the first half's GGM / marching-cubes graphs (small, latency-bound grids on side streams) run
-        # beside the second half's decoder MLP (matrix-core bound)
-        meshes = None
+        # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first).
+        # OVERLAP_ISO: the lattice is decoded in two halves, the first half's GGM / marching-cubes graphs (small, latency-bound grids on
+        # side streams) run beside the second half's decoder MLP (matrix-core bound)
+        job = None
         if auto_level or B < 4 or not OVERLAP_ISO:
             wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
             if not auto_level:
-                meshes = mcu.wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level, gradient_sigma, gradient_direction)
+                job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, bank=iso_bank)
+                job.enqueue(wnf_all)
         else:
-            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction)
+            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, bank=iso_bank)
             parts = []
             for b0, b1 in ((0, B // 2), (B // 2, B)):
                 part = model.volume_lattice_forward(unet3d_result.select(b0, b1), volume_size)["pred_volume"]
                 job.enqueue(part)
                 parts.append(part)
             wnf_all = torch.cat(parts)
-            meshes = job.finish()
-        bad = torch.isnan(wnf_all).any()             # read by the caller after the batch's own host synchronisation
-        ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
-        results = []
-        if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
-            return None, True
+        bad = torch.isnan(wnf_all).any()             # read after the batch's own host synchronisation
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
         bins = model.pointnet2_nocs.nocs_bins
         glog_all = pointnet2_result["global_logits"].reshape(B, bins, 3)
         grip_global = torch.argmax(glog_all, dim=1).to(torch.float32) * (1.0 / (bins - 1))
         conf_global = torch.softmax(glog_all, dim=1)
         sizes = list(nocs_data.sizes)
-        grip_idx = None
+        grip_nocs = None
         if len(set(sizes)) == 1 and sizes[0] > 0:          # equal clouds: one batched arg-min (ragged batches fall back to per-garment)
             grip_idx = torch.argmin(torch.norm(batch.pos.view(B, sizes[0], 3), dim=2), dim=1) + torch.arange(B, device=batch.pos.device) * sizes[0]
             grip_nocs = nocs_data.pos[grip_idx]
+        return dict(pointnet2_result=pointnet2_result, unet3d_result=unet3d_result, wnf_all=wnf_all, job=job, bad=bad,
+                    grip_global=grip_global, conf_global=conf_global, grip_nocs=grip_nocs)
+
+
+def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
+    """the host-synchronising rest, on the current stream: vertex / face counts of the batch (one device-to-host copy), per garment
+    the mesh slices, the GGM look-up and the surface decoders.  -> (results, device bool: the WNF holds a NaN); stop_on_nan: ->
+    (None, True) before the per-garment tail when it does"""
+    with torch.no_grad():
+        pointnet2_result, unet3d_result, wnf_all, bad = st["pointnet2_result"], st["unet3d_result"], st["wnf_all"], st["bad"]
+        nocs_data = pointnet2_result["nocs_data"]
+        B = nocs_data.num_graphs
+        meshes = st["job"].finish() if st["job"] is not None else None
+        ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
+        results = []
+        if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
+            return None, True
+        grip_global, conf_global, grip_nocs = st["grip_global"], st["conf_global"], st["grip_nocs"]
         for b in range(B):
             wnf = wnf_all[b]
             res = dict(wnf_volume=wnf)
@@ -134,10 +150,84 @@ def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_s
             res.update(pred_nocs=nocs_data.pos[sl], pred_nocs_confidence=nocs_data.pred_confidence[sl],
                        pred_nocs_logits=pointnet2_result["per_point_logits"][sl], input_points=batch.pos[sl], input_rgb=batch.x[sl])
             res.update(pred_global_nocs_grip_point=grip_global[b], pred_global_confidence=conf_global[b],
-                       pred_nocs_grip_point=grip_nocs[b] if grip_idx is not None else nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
+                       pred_nocs_grip_point=grip_nocs[b] if grip_nocs is not None else nocs_data.pos[sl][torch.argmin(torch.norm(batch.pos[sl], dim=1))],
                        global_feature=pointnet2_result["global_feature"][b])
             results.append(res)
         return results, bad
+
+
+def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
+    """-> (results, device bool: the WNF holds a NaN); stop_on_nan: -> (None, True) before the per-garment tail when it does"""
+    st = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level)
+    return _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan)
+
+
+_TAIL_STREAMS = {}
+
+
+class PredictJob:
+    """predict_batch in two halves, for a stream of batches: the constructor queues everything that needs no host synchronisation
+    (PointNet++, UNet, WNF lattice on the current stream; the per-garment GGM / MC33 slot graphs on the iso side streams) and returns;
+    ``finish()`` does the rest -- the one device-to-host copy of the vertex / face counts, the mesh slices, the surface decoders --
+    on a tail stream of its own, so that it waits for THIS batch's iso-surfaces only, not for whatever the caller has queued on the
+    main stream since.  Begin batch k+1, then finish batch k: the latency-bound tail of k (small grids, host round trip) and the
+    16-workgroup farthest-point sampling of k+1 fill each other's idle CUs, and the host's launch gaps disappear behind queued work.
+    Two banks of iso slot buffers (``bank`` = 1 + (k & 1); predict_batch uses bank 0) keep batch k's marching-cubes outputs intact
+    while k+1's are produced: a bank belongs to its job until finish().
+    Same results as predict_batch, bit for bit (tests/test_gpu_api.py)."""
+
+    def __init__(self, model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
+                 use_hole_prediction=False, bank=1):
+        from . import ops
+        self.model, self.batch = model, batch
+        self.args = (volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction)
+        self.split = ops.CONV_MODE != ops.CONV_FP32 or ops.DECODE_MODE != "fp32"
+        self.device = batch.pos.device
+        self.main = torch.cuda.current_stream(self.device)
+        self.state = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, False, iso_bank=bank)
+        self.ready = torch.cuda.Event()
+        self.ready.record(self.main)
+
+    def finish(self, host=False):
+        """-> what predict_batch returns; host=True: -> [to_host(r) for r in results], copied on the tail stream (the copies wait for this
+        batch only, not for the next batch's dense path on the caller's stream)"""
+        volume_size, level, sigma, direction, hole = self.args
+        tail = _TAIL_STREAMS.get(str(self.device))
+        if tail is None:
+            tail = _TAIL_STREAMS[str(self.device)] = torch.cuda.Stream(device=self.device)
+        tail.wait_event(self.ready)
+        with torch.cuda.stream(tail):
+            results, bad = _tail_phase(self.model, self.batch, self.state, level, sigma, direction, hole, False, self.split)
+            if host and results is not None and not (self.split and bool(bad)):
+                results = [to_host(r) for r in results]
+                self.state = None
+                return results
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(tail)                       # the caller's stream sees finished results; main-stream memory the tail read is safe to recycle
+        if self.split and (results is None or bool(bad)):
+            self.state = None
+            results = predict_batch(self.model, self.batch, volume_size, level, sigma, direction, hole, False)   # (takes the fp32 re-run path)
+            return [to_host(r) for r in results] if host else results
+        for r in results:                           # allocated on the tail stream, consumed on the caller's
+            for v in r.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+        self.state = None
+        return results
+
+
+def predict_stream(model, batches, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
+                   use_hole_prediction=False):
+    """generator over an iterable of batches -> the predict_batch result of each, in order, with one batch in flight behind the one
+    being finished (PredictJob)"""
+    prev = None
+    for k, batch in enumerate(batches):
+        job = PredictJob(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, bank=1 + (k & 1))
+        if prev is not None:
+            yield prev.finish()
+        prev = job
+    if prev is not None:
+        yield prev.finish()
 
 
 def to_host(res):

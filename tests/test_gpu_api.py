@@ -152,3 +152,45 @@ def test_non_default_device():
     assert out1["wnf_volume"].device == torch.device("cuda:1")
     assert torch.equal(out0["wnf_volume"].cpu(), out1["wnf_volume"].cpu()) and torch.equal(out0["faces"].cpu(), out1["faces"].cpu())
     torch.cuda.set_device(0)
+
+
+def test_predict_stream_equals_predict_batch():
+    """predict.PredictJob / predict_stream (batch k+1's dense path queued before batch k's host-synchronising tail, tails on their own
+    stream, two banks of iso slot buffers): every garment of every batch bit-equal to predict_batch run batch by batch -- including a
+    batch whose meshes are empty at the fixed level (placeholder path) and the hole-prediction head"""
+    from garmentnets_amd.predict import PredictJob, predict_stream
+    hp = S.default_hparams(grid=32, reduce_method="mean", mc_surface=True)
+    model = _model(hp, 3)
+    batches = []
+    for k in range(5):
+        n = 2000 + 500 * (k % 2)
+        x, pos, batch = S.synthetic_cloud(3, n, seed=40 + k)
+        batches.append(Batch(sizes=[n] * 3, x=x, pos=pos, batch=batch).to(DEV))
+    # a level every synthetic WNF straddles: the mid level of the first batch's first garment (fixed level: the pipelined path has no auto_level)
+    probe = predict_batch(model, batches[0], volume_size=32, auto_level=True)
+    w = probe[0]["wnf_volume"]
+    level = 0.5 * (float(w.min()) + float(w.max()))
+    ref = [predict_batch(model, b, volume_size=32, iso_surface_level=level, use_hole_prediction=True) for b in batches]
+    got = list(predict_stream(model, batches, volume_size=32, iso_surface_level=level, use_hole_prediction=True))
+    torch.cuda.synchronize()
+    assert len(got) == len(ref)
+    n_real = 0
+    for rb, gb in zip(ref, got):
+        assert len(rb) == len(gb)
+        for r, g in zip(rb, gb):
+            assert set(r) == set(g)
+            for k in r:
+                a, b = r[k], g[k]
+                assert a.shape == b.shape and a.dtype == b.dtype, k
+                assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), k
+            n_real += int(not torch.isnan(r["verts"]).any())
+    assert n_real >= 3
+    # twice over the same batches (slot banks and the tail stream reused), interleaved with a plain predict_batch on the main stream
+    j0 = PredictJob(model, batches[1], 32, level, bank=1)      # (predict_batch itself uses bank 0)
+    j1 = PredictJob(model, batches[2], 32, level, bank=2)
+    mid = predict_batch(model, batches[3], volume_size=32, iso_surface_level=level)
+    r0, r1 = j0.finish(), j1.finish()
+    for rb, gb in ((ref[1], r0), (ref[2], r1), (ref[3], mid)):
+        for r, g in zip(rb, gb):
+            assert torch.equal(r["faces"], g["faces"]) and torch.equal(torch.nan_to_num(r["verts"], nan=-7.0), torch.nan_to_num(g["verts"], nan=-7.0))
+            assert torch.equal(torch.nan_to_num(r["warp_field"], nan=-7.0), torch.nan_to_num(g["warp_field"], nan=-7.0))
