@@ -110,6 +110,10 @@ def _iso_streams(device, n):
 
 ISO_STREAMS = int(os.environ.get("GARMENTNETS_ISO_STREAMS", "4"))     # concurrent slot-graph replays of wnf_batch_to_meshes_gpu (1 = in stream)
 USE_ISO_GRAPHS = True      # wnf_batch_to_meshes_gpu replays a captured graph per garment slot (False: plain launches)
+# the default: GGM / min-max / MC33 of the whole batch in ONE set of launches (gn_*_batch: a volume per blockIdx.y, ~25 launches per
+# batch instead of ~25 per garment) on the caller's stream -- no slot graphs, no side streams, no copies out of slot buffers.
+# GARMENTNETS_ISO_BATCHED=0: the per-garment slot graphs on side streams
+ISO_BATCHED = os.environ.get("GARMENTNETS_ISO_BATCHED", "1") == "1"
 
 
 class IsoBatchJob:
@@ -127,11 +131,31 @@ class IsoBatchJob:
         self.cap_v = max(4096, int(6 * self.Q ** 2))
         self.cap_f = 2 * self.cap_v + 64
         self.vols, self.ggms, self.mcs, self.recs, self.lanes_used = [], [], [], [], []
+        self.padded, self.max_nv = [], 0             # batched path: the (Bp, cap_v, 3) float32 query buffers; largest vertex count of the batch
+        self.own_buffers = False                     # True: the outputs are this job's own allocations (batched path), not slot buffers
         self.bank = int(bank)                        # a second set of slot buffers for a caller that keeps two batches in flight (predict.PredictJob)
 
     def enqueue(self, wnf_part):
         B0, Bp = len(self.vols), wnf_part.shape[0]
         dev = wnf_part.device
+        if ISO_BATCHED and Bp > 0 and (self.Q ** 3) % 4 == 0:
+            vols = wnf_part.float().contiguous()
+            ggm = ops.ggm3d_batch(vols, self.sigma)
+            mc = ops.mc33_batch(vols, self.level, self.cap_v, self.cap_f)           # verts, faces, normals, values, counts (device)
+            rec = torch.cat((ops.minmax_batch(vols).double(), mc[4].double()), dim=1)
+            # the vertex look-ups on the padded (Bp, cap_v) buffers, before the counts are known (rows past a garment's count are zeros)
+            spacing = 1 / (self.Q - 1)
+            vf32 = ops.scale_verts(mc[0].view(-1, 3), spacing).view(Bp, self.cap_v, 3)
+            v64 = mc[0].double() * spacing
+            vgm = ops.gather_nn_batch(ggm, mc[0], spacing)
+            for i in range(Bp):
+                self.vols.append(vols[i])
+                self.ggms.append(ggm[i])
+                self.mcs.append((mc[0][i], mc[1][i], mc[2][i], mc[3][i], mc[4][i], vf32[i], v64[i], vgm[i]))
+                self.recs.append(rec[i])
+            self.own_buffers = True
+            self.padded.append(vf32)
+            return
         main = torch.cuda.current_stream(dev)
         # the garments are independent and one 128^3 volume does not fill 256 CUs (GGM / classify / scan / emit are small grids with
         # dependent launches in between): the slot graphs are replayed round-robin on a few side streams
@@ -194,13 +218,28 @@ class IsoBatchJob:
                 continue
             mc = self.mcs[b]
             verts_vox, faces, normals, values = mc[0][:nv], mc[1][:nf], mc[2][:nv], mc[3][:nv]
-            if USE_ISO_GRAPHS:   # slot b's static buffers are overwritten by the next replay: hand out copies (a few MB per garment)
+            if self.own_buffers:                       # batched path: everything is a slice of the batch's buffers, no launch per garment
+                self.max_nv = max(self.max_nv, nv)
+                if self.direction == "descent":
+                    faces = torch.flip(faces, dims=[1])
+                out.append(dict(verts=mc[6][:nv], verts_f32=mc[5][:nv], faces=faces, normals=normals, volume_value=values,
+                                volume_gradient_magnitude=mc[7][:nv], ggm=self.ggms[b]))
+                continue
+            if USE_ISO_GRAPHS and not self.own_buffers:   # slot b's static buffers are overwritten by the next replay: hand out copies (a few MB per garment)
                 faces, normals, values = faces.clone(), normals.clone(), values.clone()
             if self.direction == "descent":
                 faces = torch.flip(faces, dims=[1])
             out.append(dict(verts=verts_vox.double() * spacing, verts_f32=ops.scale_verts(verts_vox, spacing), faces=faces, normals=normals,
                             volume_value=values, volume_gradient_magnitude=ops.gather_nn(self.ggms[b], verts_vox, spacing), ggm=self.ggms[b]))
         return out
+
+
+    def padded_queries(self):
+        """after finish(), batched path with one enqueue: -> (B, max_nv, 3) float32, garment b's vertices in rows [0, nv_b) and zeros
+        behind them -- one decoder launch for the whole batch's surface queries instead of one per garment; None when not applicable"""
+        if not self.own_buffers or len(self.padded) != 1 or self.max_nv == 0:
+            return None
+        return self.padded[0][:, :self.max_nv].contiguous()
 
 
 def wnf_batch_to_meshes_gpu(wnf_all, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):

@@ -27,8 +27,13 @@ struct GgmWeights {
 
 // correlate1d along `axis`, edge-replicate, fp64 accumulation in scipy's operation order, fp32 store
 __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1,
-                                                            int n2, int axis, GgmWeights gw) {
+                                                            int n2, int axis, GgmWeights gw, int accum) {
+    // accum = 0: out = correlation.  1 / 2 / 3: the fp32 correlation value t is squared and accumulated instead (first / middle /
+    // last axis term of the gradient magnitude: out = t*t | out += t*t | out = sqrt(out + t*t)) -- no pass of its own over
+    // a stored t
     const int64_t tot = (int64_t)n0 * n1 * n2;
+    in += (int64_t)blockIdx.y * tot;                // batched: one volume per blockIdx.y
+    out += (int64_t)blockIdx.y * tot;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tot) return;
     const int i2 = (int)(t % n2), i1 = (int)((t / n2) % n1), i0 = (int)(t / ((int64_t)n1 * n2));
@@ -53,18 +58,12 @@ __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restr
         acc = 0.0;
         for (int j = -r; j <= r; ++j) acc = __dadd_rn(acc, __dmul_rn(at(j), gw.w[r + j]));
     }
-    out[t] = (float)acc;
-}
-
-// out = (first ? 0 : out) + t*t ; last: out = sqrt(out)
-__global__ __launch_bounds__(256) void ggm_accum_kernel(const float *__restrict__ t, float *__restrict__ out, int64_t tot, int first,
-                                                        int last) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= tot) return;
-    float sq = __fmul_rn(t[i], t[i]);
-    float v = first ? sq : __fadd_rn(out[i], sq);
+    const float tv = (float)acc;
+    if (accum == 0) { out[t] = tv; return; }
+    const float sq = __fmul_rn(tv, tv);
+    const float v = accum == 1 ? sq : __fadd_rn(out[t], sq);
     // correctly rounded fp32 sqrt (numpy.sqrt): fp64 sqrt of an fp32 value rounds to the same fp32 result
-    out[i] = last ? (float)__dsqrt_rn((double)v) : v;
+    out[t] = accum == 3 ? (float)__dsqrt_rn((double)v) : v;
 }
 
 static void ggm_kernel1d(double sigma, int order, int radius, GgmWeights &g) {
@@ -87,34 +86,40 @@ static void ggm_kernel1d(double sigma, int order, int radius, GgmWeights &g) {
     g.symmetric = sym ? 1 : (anti ? -1 : 0);
 }
 
-extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
-    GN_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
+extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
+    GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
     const int radius = (int)(4.0 * sigma + 0.5);
     GN_REQUIRE(radius >= 1 && radius <= 32, "gn_ggm3d: unsupported sigma");
+    if (batch == 0) return GN_OK;
     GgmWeights w0, w1;
     ggm_kernel1d(sigma, 0, radius, w0);
     ggm_kernel1d(sigma, 1, radius, w1);
     const int64_t tot = (int64_t)n0 * n1 * n2;
-    float *t1 = tmp, *t2 = tmp + tot;
+    float *t1 = tmp, *t2 = tmp + (int64_t)batch * tot;
     hipStream_t st = gn_stream(stream);
-    dim3 grid((unsigned)gn_cdiv(tot, 256)), block(256);
-    for (int axis = 0; axis < 3; ++axis) {
-        const float *src = vol;
-        float *dst = t1;
-        for (int a = 0; a < 3; ++a) {
-            hipLaunchKernelGGL(ggm_correlate_kernel, grid, block, 0, st, src, dst, n0, n1, n2, a, a == axis ? w1 : w0);
-            src = dst;
-            dst = (dst == t1) ? t2 : t1;
-        }
-        hipLaunchKernelGGL(ggm_accum_kernel, grid, block, 0, st, src, out, tot, axis == 0, axis == 2);
-    }
+    dim3 grid((unsigned)gn_cdiv(tot, 256), (unsigned)batch), block(256);
+    // scipy: for axis d, correlate along axes 0, 1, 2 in turn (derivative kernel on d, Gaussian on the others, fp32 between the passes),
+    // square, accumulate in the order d = 0, 1, 2, square root.  The chains of d = 1 and d = 2 both start with the Gaussian along
+    // axis 0 (computed once), and every chain's last pass accumulates directly: 8 passes over the volume instead of 12.
+#define GGM_PASS(SRC, DST, AXIS, W, ACC) hipLaunchKernelGGL(ggm_correlate_kernel, grid, block, 0, st, (const float *)(SRC), DST, n0, n1, n2, AXIS, W, ACC)
+    GGM_PASS(vol, t1, 0, w1, 0); GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w0, 1);     // d = 0
+    GGM_PASS(vol, t1, 0, w0, 0);                                                                // shared by d = 1, 2
+    GGM_PASS(t1, t2, 1, w1, 0); GGM_PASS(t2, out, 2, w0, 2);                                    // d = 1
+    GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w1, 3);                                    // d = 2
+#undef GGM_PASS
     GN_LAUNCH_CHECK("gn_ggm3d");
     return GN_OK;
+}
+
+extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
+    return gn_ggm3d_batch(vol, 1, n0, n1, n2, sigma, tmp, out, stream);
 }
 
 // ================================================================================================ min / max
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out_enc) {
     __shared__ float smn[4], smx[4];
+    x += (int64_t)blockIdx.y * n;                   // batched: n elements and one (min, max) pair per blockIdx.y (n % 4 == 0 when batched)
+    out_enc += 2 * blockIdx.y;
     float mn = 3.4e38f, mx = -3.4e38f;
     const int64_t n4 = n >> 2;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -145,8 +150,9 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
         atomicMax(&out_enc[1], emx);
     }
 }
-__global__ void minmax_init_kernel(unsigned *o) { o[0] = 0xffffffffu; o[1] = 0u; }
+__global__ void minmax_init_kernel(unsigned *o) { o += 2 * blockIdx.x; o[0] = 0xffffffffu; o[1] = 0u; }
 __global__ void minmax_decode_kernel(unsigned *o) {
+    o += 2 * blockIdx.x;
     for (int k = 0; k < 2; ++k) {
         unsigned e = o[k];
         unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
@@ -154,18 +160,22 @@ __global__ void minmax_decode_kernel(unsigned *o) {
     }
 }
 
-extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) {
-    GN_REQUIRE(n > 0, "gn_minmax: empty input");
+extern "C" int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2, void *stream) {
+    GN_REQUIRE(n > 0 && batch >= 0 && batch <= 65535, "gn_minmax: empty input");
+    GN_REQUIRE(batch <= 1 || (n & 3) == 0, "gn_minmax_batch: n must be a multiple of 4 for batch > 1");
+    if (batch == 0) return GN_OK;
     hipStream_t st = gn_stream(stream);
     unsigned *o = reinterpret_cast<unsigned *>(out2);
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, o);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(batch), dim3(1), 0, st, o);
     GN_REQUIRE(((uintptr_t)x & 15) == 0, "gn_minmax: x must be 16-byte aligned");
     int blocks = (int)(gn_cdiv(n, 1024) < 512 ? gn_cdiv(n, 1024) : 512);
-    hipLaunchKernelGGL(minmax_kernel, dim3(blocks), dim3(256), 0, st, x, n, o);
-    hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, st, o);
+    hipLaunchKernelGGL(minmax_kernel, dim3(blocks, batch), dim3(256), 0, st, x, n, o);
+    hipLaunchKernelGGL(minmax_decode_kernel, dim3(batch), dim3(1), 0, st, o);
     GN_LAUNCH_CHECK("gn_minmax");
     return GN_OK;
 }
+
+extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) { return gn_minmax_batch(x, 1, n, out2, stream); }
 
 // ================================================================================================ MC33
 __device__ const int8_t MC_LUT_G[MC_LUT_BYTES] = MC_LUT_INITIALIZER;
@@ -181,6 +191,8 @@ struct McDims {
     int n0, n1, n2;   // volume (axis0 = z, axis1 = y, axis2 = x)
     int c0, c1, c2;   // cells
     int64_t ncells, nvox;
+    // batched launches (blockIdx.y = volume): element strides between consecutive volumes' workspaces / outputs (0 for one volume)
+    int64_t s_cinfo, s_cnt, s_edge, s_bsum, s_verts, s_faces;
 };
 
 // corner values minus level, Lewiner numbering: v0=(0,0,0) v1=(x+1) v2=(x+1,y+1) v3=(y+1) v4..v7 at z+1
@@ -382,15 +394,25 @@ __device__ __forceinline__ int64_t mc_edge_slot(const McDims &d, int x, int y, i
 __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restrict__ vol, McDims d, double level,
                                                           int32_t *__restrict__ cinfo, unsigned long long *__restrict__ counts) {
     __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    mc_stage_lut(lut);
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; counts += blockIdx.y * d.s_cnt;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= d.ncells) return;
+    const bool inside = ci < d.ncells;
     const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
     double v[8];
-    mc_load_cell(vol, d, x, y, z, level, v);
     int index = 0;
+    if (inside) {
+        mc_load_cell(vol, d, x, y, z, level, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) index |= (v[i] > 0.0) ? (1 << i) : 0;
+        for (int i = 0; i < 8; ++i) index |= (v[i] > 0.0) ? (1 << i) : 0;
+    }
+    // the 13.4 KB of tables are staged only by workgroups that hold a cell the surface crosses (a few per cent of them: the staging,
+    // done by every workgroup, was most of this kernel's time)
+    if (!__syncthreads_or(index != 0 && index != 255)) {
+        if (inside) { cinfo[ci] = -1; counts[ci] = 0; }
+        return;
+    }
+    mc_stage_lut(lut);
+    if (!inside) return;
     int info = -1;
     unsigned long long cnt = 0;
     if (index != 0 && index != 255) {
@@ -431,7 +453,8 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
 }
 
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const unsigned long long *__restrict__ in, int64_t n,
-                                                              unsigned long long *__restrict__ bsum) {
+                                                              unsigned long long *__restrict__ bsum, int64_t s_in, int64_t s_bsum) {
+    in += blockIdx.y * s_in; bsum += blockIdx.y * s_bsum;
     const int64_t i0 = (int64_t)blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
     unsigned long long s = 0;
     for (int k = 0; k < 4; ++k)
@@ -442,7 +465,8 @@ __global__ __launch_bounds__(256) void scan_block_sums_kernel(const unsigned lon
 }
 
 __global__ __launch_bounds__(256) void scan_top_kernel(unsigned long long *__restrict__ bsum, int64_t nb,
-                                                       unsigned long long *__restrict__ total_out) {
+                                                       unsigned long long *__restrict__ total_out, int64_t s_bsum) {
+    bsum += blockIdx.y * s_bsum; total_out += blockIdx.y * s_bsum;
     __shared__ unsigned long long carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -461,7 +485,8 @@ __global__ __launch_bounds__(256) void scan_top_kernel(unsigned long long *__res
 
 __global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned long long *__restrict__ in, int64_t n,
                                                          const unsigned long long *__restrict__ bsum,
-                                                         unsigned long long *__restrict__ out) {
+                                                         unsigned long long *__restrict__ out, int64_t s_in, int64_t s_bsum) {
+    in += blockIdx.y * s_in; out += blockIdx.y * s_in; bsum += blockIdx.y * s_bsum;
     const int64_t i0 = (int64_t)blockIdx.x * SCAN_ELEMS + threadIdx.x * 4;
     unsigned long long v[4], s = 0;
     for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? in[i0 + k] : 0; s += v[k]; }
@@ -502,17 +527,26 @@ __device__ __forceinline__ void mc_bit_order(const double *v, double *vv) {
     vv[0] = v[0]; vv[1] = v[1]; vv[2] = v[3]; vv[3] = v[2]; vv[4] = v[4]; vv[5] = v[5]; vv[6] = v[7]; vv[7] = v[6];
 }
 
+// surface cells are a few per cent of the cells: a workgroup scans MC_CELL_SLOTS cells per thread, queues the ones the surface crosses
+// in LDS and works them off with consecutive lanes (as mc_attrs_kernel does for the edge table)
+#define MC_CELL_SLOTS 8
+__device__ __forceinline__ unsigned mc_queue_cells(const int32_t *__restrict__ cinfo, const McDims &d, int64_t wg0, unsigned short *queue, unsigned *qn) {
+    if (threadIdx.x == 0) *qn = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MC_CELL_SLOTS; ++i) {
+        const int local = i * 256 + threadIdx.x;
+        const int64_t ci = wg0 + local;
+        if (ci < d.ncells && cinfo[ci] >= 0) queue[atomicAdd(qn, 1u)] = (unsigned short)local;
+    }
+    __syncthreads();
+    return *qn;
+}
+
 // owners: vertex ids, positions, edge table
-__global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restrict__ vol, McDims d, double level,
-                                                          const int32_t *__restrict__ cinfo,
-                                                          const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
-                                                          float *__restrict__ verts, int64_t cap_v) {
-    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    mc_stage_lut(lut);
-    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= d.ncells) return;
-    const int info = cinfo[ci];
-    if (info < 0) return;
+__device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, const McDims &d, double level, const int8_t *lut, int64_t ci, int info,
+                                                const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
+                                                float *__restrict__ verts, int64_t cap_v) {
     const int row = info & 0xffff, ntri = info >> 16;
     const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
     const unsigned owned = mc_owned_mask(x, y, z);
@@ -564,34 +598,52 @@ __global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restric
     }
 }
 
+__global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restrict__ vol, McDims d, double level,
+                                                          const int32_t *__restrict__ cinfo,
+                                                          const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
+                                                          float *__restrict__ verts, int64_t cap_v) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    __shared__ unsigned short queue[256 * MC_CELL_SLOTS];
+    __shared__ unsigned qn;
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; offs += blockIdx.y * d.s_cnt; edge_vid += blockIdx.y * d.s_edge; verts += blockIdx.y * d.s_verts;
+    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_CELL_SLOTS);
+    const unsigned cnt = mc_queue_cells(cinfo, d, wg0, queue, &qn);
+    if (cnt == 0) return;                           // (workgroup-uniform) no surface cell here: no table staging
+    mc_stage_lut(lut);
+    for (unsigned k = threadIdx.x; k < cnt; k += 256) {
+        const int64_t ci = wg0 + queue[k];
+        mc_vertices_one(vol, d, level, lut, ci, cinfo[ci], offs, edge_vid, verts, cap_v);
+    }
+}
+
 __global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *__restrict__ cinfo,
                                                        const unsigned long long *__restrict__ offs,
                                                        const int32_t *__restrict__ edge_vid, int32_t *__restrict__ faces, int64_t cap_f) {
     __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    __shared__ unsigned short queue[256 * MC_CELL_SLOTS];
+    __shared__ unsigned qn;
+    cinfo += blockIdx.y * d.s_cinfo; offs += blockIdx.y * d.s_cnt; edge_vid += blockIdx.y * d.s_edge; faces += blockIdx.y * d.s_faces;
+    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_CELL_SLOTS);
+    const unsigned cnt = mc_queue_cells(cinfo, d, wg0, queue, &qn);
+    if (cnt == 0) return;
     mc_stage_lut(lut);
-    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= d.ncells) return;
-    const int info = cinfo[ci];
-    if (info < 0) return;
-    const int row = info & 0xffff, ntri = info >> 16;
-    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
-    const int64_t t0 = (int64_t)(offs[ci] & 0xffffffffull);
-    for (int k = 0; k < ntri * 3; ++k) {
-        const int64_t f = t0 + k / 3;
-        if (f < cap_f) faces[f * 3 + k % 3] = edge_vid[mc_edge_slot(d, x, y, z, lut[row + k])];
+    for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+        const int64_t ci = wg0 + queue[q];
+        const int info = cinfo[ci];
+        const int row = info & 0xffff, ntri = info >> 16;
+        const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+        const int64_t t0 = (int64_t)(offs[ci] & 0xffffffffull);
+        for (int k = 0; k < ntri * 3; ++k) {
+            const int64_t f = t0 + k / 3;
+            if (f < cap_f) faces[f * 3 + k % 3] = edge_vid[mc_edge_slot(d, x, y, z, lut[row + k])];
+        }
     }
 }
 
 // per-vertex gather of normals / values over the adjacent cells in sweep order.  One thread per (voxel, slot).
-__global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level,
-                                                       const int32_t *__restrict__ cinfo, const int32_t *__restrict__ edge_vid,
-                                                       float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
-    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    mc_stage_lut(lut);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.nvox * 4) return;
-    const int64_t vid = edge_vid[t];
-    if (vid < 0 || vid >= cap_v) return;
+// one (voxel, slot) entry t that holds vertex vid
+__device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
+                                            const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
     const int j = (int)(t & 3);
     const int64_t vx = t >> 2;
     const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
@@ -662,52 +714,113 @@ __global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__
     values[vid] = val;
 }
 
-__global__ void mc_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts_dev) {
+// The edge table is almost empty (about 1 entry in 130 holds a vertex): a workgroup scans 16 entries per thread, queues the occupied
+// ones in LDS and then works them off with consecutive lanes -- one entry per thread left 63 of 64 lanes idle through the long fp64
+// body (the longest kernel of the iso stage), and 524 k workgroups per batch to launch.
+#define MC_ATTR_SLOTS 16
+__global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level,
+                                                       const int32_t *__restrict__ cinfo, const int32_t *__restrict__ edge_vid,
+                                                       float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    __shared__ unsigned short queue[256 * MC_ATTR_SLOTS];
+    __shared__ unsigned qn;
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; edge_vid += blockIdx.y * d.s_edge; normals += blockIdx.y * d.s_verts; values += blockIdx.y * (d.s_verts / 3);
+    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_ATTR_SLOTS), n = d.nvox * 4;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MC_ATTR_SLOTS; ++i) {
+        const int local = i * 256 + threadIdx.x;
+        const int64_t t = wg0 + local;
+        const int64_t vid = t < n ? edge_vid[t] : -1;
+        if (vid >= 0 && vid < cap_v) queue[atomicAdd(&qn, 1u)] = (unsigned short)local;   // (any order: every entry writes its own vertex)
+    }
+    __syncthreads();
+    const unsigned cnt = qn;
+    if (cnt == 0) return;                           // (workgroup-uniform) no vertex in these 1024 voxels: no table staging
+    mc_stage_lut(lut);
+    for (unsigned k = threadIdx.x; k < cnt; k += 256) {
+        const int64_t t = wg0 + queue[k];
+        mc_attr_one(vol, d, level, cinfo, lut, t, edge_vid[t], normals, values);
+    }
+}
+
+__global__ void mc_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts_dev, int64_t s_bsum) {
+    total += blockIdx.x * s_bsum; counts_dev += 2 * blockIdx.x;
     counts_dev[0] = (int64_t)(*total >> 32);
     counts_dev[1] = (int64_t)(*total & 0xffffffffull);
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t gn_mc33_workspace_bytes(int n0, int n1, int n2) {
-    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+static size_t mc33_ws_one(int n0, int n1, int n2) {
     const size_t ncells = (size_t)(n0 - 1) * (n1 - 1) * (n2 - 1), nvox = (size_t)n0 * n1 * n2;
     const size_t nb = (ncells + SCAN_ELEMS - 1) / SCAN_ELEMS;
-    return align256(ncells * 4) + 2 * align256(ncells * 8) + align256(nvox * 16) + align256((nb + 1) * 8) + 256;
+    return align256(ncells * 4) + 2 * align256(ncells * 8) + align256(nvox * 16) + align256((nb + 1) * 8);
 }
 
-extern "C" int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
-                       int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev,
-                       void *stream) {
+extern "C" size_t gn_mc33_workspace_bytes(int n0, int n1, int n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+    return mc33_ws_one(n0, n1, n2) + 256;
+}
+
+extern "C" size_t gn_mc33_batch_workspace_bytes(int batch, int n0, int n1, int n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2 || batch < 1) return 0;
+    return (size_t)batch * mc33_ws_one(n0, n1, n2) + 256;
+}
+
+// `batch` volumes of the same shape and level in one set of launches (blockIdx.y = volume): vol [batch][n0][n1][n2], verts / normals
+// [batch][cap_v][3], faces [batch][cap_f][3], values [batch][cap_v], counts_dev [batch][2].  The workspace is laid out array by array
+// ([batch] cell infos | [batch] counts | [batch] offsets | [batch] edge tables | [batch] block sums) so that one memset clears every
+// edge table.  Every volume's result is what gn_mc33 gives for it alone.
+extern "C" int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                             int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream) {
     GN_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "gn_mc33: input volume must be at least 2x2x2");
-    GN_REQUIRE(ws != nullptr && ws_bytes >= gn_mc33_workspace_bytes(n0, n1, n2), "gn_mc33: workspace too small");
+    GN_REQUIRE(batch >= 0 && batch <= 65535, "gn_mc33_batch: bad batch");
+    if (batch == 0) return GN_OK;
+    GN_REQUIRE(ws != nullptr && ws_bytes >= gn_mc33_batch_workspace_bytes(batch, n0, n1, n2), "gn_mc33: workspace too small");
     GN_REQUIRE(cap_v >= 0 && cap_f >= 0, "gn_mc33: bad capacities");
     McDims d;
     d.n0 = n0; d.n1 = n1; d.n2 = n2; d.c0 = n0 - 1; d.c1 = n1 - 1; d.c2 = n2 - 1;
     d.ncells = (int64_t)d.c0 * d.c1 * d.c2;
     d.nvox = (int64_t)n0 * n1 * n2;
     const int64_t nb = gn_cdiv(d.ncells, SCAN_ELEMS);
+    d.s_cinfo = (int64_t)(align256(d.ncells * 4) / 4);
+    d.s_cnt = (int64_t)(align256(d.ncells * 8) / 8);
+    d.s_edge = (int64_t)(align256(d.nvox * 16) / 4);
+    d.s_bsum = (int64_t)(align256((nb + 1) * 8) / 8);
+    d.s_verts = cap_v * 3;
+    d.s_faces = cap_f * 3;
     char *p = (char *)ws;
-    int32_t *cinfo = (int32_t *)p; p += align256(d.ncells * 4);
-    unsigned long long *counts = (unsigned long long *)p; p += align256(d.ncells * 8);
-    unsigned long long *offs = (unsigned long long *)p; p += align256(d.ncells * 8);
-    int32_t *edge_vid = (int32_t *)p; p += align256(d.nvox * 16);
-    unsigned long long *bsum = (unsigned long long *)p; p += align256((nb + 1) * 8);
+    int32_t *cinfo = (int32_t *)p; p += (size_t)batch * d.s_cinfo * 4;
+    unsigned long long *counts = (unsigned long long *)p; p += (size_t)batch * d.s_cnt * 8;
+    unsigned long long *offs = (unsigned long long *)p; p += (size_t)batch * d.s_cnt * 8;
+    int32_t *edge_vid = (int32_t *)p; p += (size_t)batch * d.s_edge * 4;
+    unsigned long long *bsum = (unsigned long long *)p;
     unsigned long long *total = bsum + nb;
     hipStream_t st = gn_stream(stream);
-    GN_HIP(hipMemsetAsync(edge_vid, 0xff, (size_t)d.nvox * 16, st), "gn_mc33(memset)");
-    const dim3 blk(256), gcell((unsigned)gn_cdiv(d.ncells, 256));
+    GN_HIP(hipMemsetAsync(edge_vid, 0xff, (size_t)batch * d.s_edge * 4, st), "gn_mc33(memset)");
+    const unsigned nby = (unsigned)batch;
+    const dim3 blk(256), gcell((unsigned)gn_cdiv(d.ncells, 256), nby);
     hipLaunchKernelGGL(mc_classify_kernel, gcell, blk, 0, st, vol, d, level, cinfo, counts);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), blk, 0, st, counts, d.ncells, bsum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), blk, 0, st, bsum, nb, total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), blk, 0, st, counts, d.ncells, bsum, offs);
-    hipLaunchKernelGGL(mc_counts_kernel, dim3(1), dim3(1), 0, st, total, counts_dev);
-    hipLaunchKernelGGL(mc_vertices_kernel, gcell, blk, 0, st, vol, d, level, cinfo, offs, edge_vid, verts, cap_v);
-    hipLaunchKernelGGL(mc_faces_kernel, gcell, blk, 0, st, d, cinfo, offs, edge_vid, faces, cap_f);
-    hipLaunchKernelGGL(mc_attrs_kernel, dim3((unsigned)gn_cdiv(d.nvox * 4, 256)), blk, 0, st, vol, d, level, cinfo, edge_vid, normals,
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb, nby), blk, 0, st, counts, d.ncells, bsum, d.s_cnt, d.s_bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1, nby), blk, 0, st, bsum, nb, total, d.s_bsum);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb, nby), blk, 0, st, counts, d.ncells, bsum, offs, d.s_cnt, d.s_bsum);
+    hipLaunchKernelGGL(mc_counts_kernel, dim3(nby), dim3(1), 0, st, total, counts_dev, d.s_bsum);
+    const dim3 gcell8((unsigned)gn_cdiv(d.ncells, 256 * MC_CELL_SLOTS), nby);
+    hipLaunchKernelGGL(mc_vertices_kernel, gcell8, blk, 0, st, vol, d, level, cinfo, offs, edge_vid, verts, cap_v);
+    hipLaunchKernelGGL(mc_faces_kernel, gcell8, blk, 0, st, d, cinfo, offs, edge_vid, faces, cap_f);
+    hipLaunchKernelGGL(mc_attrs_kernel, dim3((unsigned)gn_cdiv(d.nvox * 4, 256 * MC_ATTR_SLOTS), nby), blk, 0, st, vol, d, level, cinfo, edge_vid, normals,
                        values, cap_v);
     GN_LAUNCH_CHECK("gn_mc33");
     return GN_OK;
+}
+
+extern "C" int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                       int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev,
+                       void *stream) {
+    GN_REQUIRE(ws != nullptr && ws_bytes >= gn_mc33_workspace_bytes(n0, n1, n2), "gn_mc33: workspace too small");
+    return gn_mc33_batch(vol, 1, n0, n1, n2, level, ws, ws_bytes, verts, faces, normals, values, cap_v, cap_f, counts_dev, stream);
 }
 
 // ================================================================================================ vertex helpers
@@ -716,6 +829,9 @@ __global__ __launch_bounds__(256) void gather_nn_kernel(const float *__restrict_
                                                         float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
+    vol += (int64_t)blockIdx.y * n0 * n1 * n2;      // batched: volume, nv vertex rows and nv outputs per blockIdx.y
+    verts_vox += (int64_t)blockIdx.y * nv * 3;
+    out += (int64_t)blockIdx.y * nv;
     int id[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -730,14 +846,19 @@ __global__ __launch_bounds__(256) void gather_nn_kernel(const float *__restrict_
     out[i] = vol[((int64_t)id[0] * n1 + id[1]) * n2 + id[2]];
 }
 
-extern "C" int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
-                            float *out, void *stream) {
-    GN_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && nv >= 0 && spacing > 0, "gn_gather_nn: bad sizes");
-    if (nv == 0) return GN_OK;
-    hipLaunchKernelGGL(gather_nn_kernel, dim3((unsigned)gn_cdiv(nv, 256)), dim3(256), 0, gn_stream(stream), vol, n0, n1, n2, verts_vox, nv,
-                       spacing, out);
+extern "C" int gn_gather_nn_batch(const float *vol, int batch, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
+                                  float *out, void *stream) {
+    GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && nv >= 0 && spacing > 0, "gn_gather_nn: bad sizes");
+    if (nv == 0 || batch == 0) return GN_OK;
+    hipLaunchKernelGGL(gather_nn_kernel, dim3((unsigned)gn_cdiv(nv, 256), (unsigned)batch), dim3(256), 0, gn_stream(stream), vol, n0, n1, n2,
+                       verts_vox, nv, spacing, out);
     GN_LAUNCH_CHECK("gn_gather_nn");
     return GN_OK;
+}
+
+extern "C" int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
+                            float *out, void *stream) {
+    return gn_gather_nn_batch(vol, 1, n0, n1, n2, verts_vox, nv, spacing, out, stream);
 }
 
 __global__ __launch_bounds__(256) void scale_verts_kernel(const float *__restrict__ in, int64_t n3, double spacing,
@@ -814,9 +935,9 @@ extern "C" int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t 
     unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws), *ex = flags + n, *bsum = ex + n, *total = bsum + nb;
     GN_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * (size_t)n, st), "gn_mesh_compact");
     hipLaunchKernelGGL(compact_mark_kernel, dim3((unsigned)gn_cdiv(F, 256)), dim3(256), 0, st, faces, on_surface, F, flags);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, nb, total);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, ex);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, (int64_t)0, (int64_t)0);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, nb, total, (int64_t)0);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, ex, (int64_t)0, (int64_t)0);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)gn_cdiv(n, 256)), dim3(256), 0, st, (const unsigned char *)verts, vert_bytes, faces, V, F,
                        flags, ex, (unsigned char *)out_verts, out_faces);
     // counts = (vertices kept, faces kept): unpack the scan total on the device

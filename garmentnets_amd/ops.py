@@ -627,6 +627,44 @@ def minmax(x):
     return out
 
 
+def ggm3d_batch(vols, sigma):
+    """ggm3d of every (n0,n1,n2) volume of a (B,n0,n1,n2) batch in one set of launches"""
+    _chk(vols, torch.float32, "vols")
+    B, n0, n1, n2 = vols.shape
+    tmp = torch.empty((2,) + tuple(vols.shape), dtype=torch.float32, device=vols.device)
+    out = torch.empty_like(vols)
+    _lib.call("gn_ggm3d_batch", _p(vols), B, n0, n1, n2, float(sigma), _p(tmp), _p(out), _stream())
+    return out
+
+
+def minmax_batch(vols):
+    """-> (B,2) float32: (min, max) of every volume of a (B,...) batch; the per-volume size must be a multiple of 4"""
+    _chk(vols, torch.float32, "vols")
+    B = vols.shape[0]
+    out = torch.empty((B, 2), dtype=torch.float32, device=vols.device)
+    if B:
+        _lib.call("gn_minmax_batch", _p(vols), B, vols.numel() // B, _p(out), _stream())
+    return out
+
+
+def mc33_batch(vols, level, cap_v, cap_f):
+    """mc33 of every volume of a (B,n0,n1,n2) batch at one level in one set of launches
+    -> verts_vox [B][cap_v][3], faces [B][cap_f][3], normals, values [B][cap_v], counts (device int64 [B][2] = V, F)"""
+    _chk(vols, torch.float32, "vols")
+    B, n0, n1, n2 = vols.shape
+    dev = vols.device
+    nbytes = _lib.load().gn_mc33_batch_workspace_bytes(B, n0, n1, n2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    verts = torch.zeros((B, cap_v, 3), dtype=torch.float32, device=dev)      # rows past a volume's vertex count stay finite (padded consumers)
+    faces = torch.empty((B, cap_f, 3), dtype=_i32, device=dev)
+    normals = torch.empty((B, cap_v, 3), dtype=torch.float32, device=dev)
+    values = torch.empty((B, cap_v), dtype=torch.float32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int64, device=dev)
+    _lib.call("gn_mc33_batch", _p(vols), B, n0, n1, n2, float(level), _p(ws), nbytes, _p(verts), _p(faces), _p(normals), _p(values), cap_v, cap_f,
+              _p(counts), _stream())
+    return verts, faces, normals, values, counts
+
+
 def mc33(vol, level, cap_v, cap_f):
     """-> verts_vox [cap_v][3], faces [cap_f][3], normals, values, counts (device int64 [2] = V, F)"""
     _chk(vol, torch.float32, "vol")
@@ -648,6 +686,15 @@ def gather_nn(vol, verts_vox, spacing):
     nv = verts_vox.shape[0]
     out = torch.empty(nv, dtype=torch.float32, device=vol.device)
     _lib.call("gn_gather_nn", _p(vol), *vol.shape, _p(verts_vox), nv, float(spacing), _p(out), _stream())
+    return out
+
+
+def gather_nn_batch(vols, verts_vox, spacing):
+    """vols (B,n0,n1,n2), verts_vox (B,M,3) padded rows -> (B,M): the nearest-voxel value of every row in its own volume"""
+    B, M = verts_vox.shape[:2]
+    out = torch.empty((B, M), dtype=torch.float32, device=vols.device)
+    _lib.call("gn_gather_nn_batch", _p(_chk(vols, torch.float32, "vols")), B, *vols.shape[1:], _p(_chk(verts_vox, torch.float32, "verts_vox")), M, float(spacing),
+              _p(out), _stream())
     return out
 
 

@@ -121,6 +121,14 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
         if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
             return None, True
         grip_global, conf_global, grip_nocs = st["grip_global"], st["conf_global"], st["grip_nocs"]
+        # surface decoders: one launch for the whole batch on the padded vertex buffer (rows past a garment's vertex count are zeros and
+        # are sliced away) when the iso-surfaces came out of the batched path; per garment otherwise
+        q_all = st["job"].padded_queries() if st["job"] is not None else None
+        warp_all = hole_all = None
+        if q_all is not None:
+            warp_all = model.surface_decoder_forward(unet3d_result, q_all)["out_features"]
+            if use_hole_prediction:
+                hole_all = model.mc_surface_decoder_forward(unet3d_result, q_all)["out_features"]
         for b in range(B):
             wnf = wnf_all[b]
             res = dict(wnf_volume=wnf)
@@ -135,11 +143,16 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
                     raise meshes[b]
                 else:
                     mesh = meshes[b]
-                u3_b = unet3d_result.select(b, b + 1)          # the 128-channel volume is never materialised on this path
-                q = mesh["verts_f32"].view(1, -1, 3)
-                mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
+                nv = mesh["verts_f32"].shape[0]
+                if warp_all is not None and nv <= warp_all.shape[1]:
+                    mesh["warp_field"] = warp_all[b, :nv]
+                    logits = hole_all[b, :nv, 0] if use_hole_prediction else None
+                else:
+                    u3_b = unet3d_result.select(b, b + 1)          # the 128-channel volume is never materialised on this path
+                    q = mesh["verts_f32"].view(1, -1, 3)
+                    mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
+                    logits = model.mc_surface_decoder_forward(u3_b, q)["out_features"].reshape(-1) if use_hole_prediction else None
                 if use_hole_prediction:
-                    logits = model.mc_surface_decoder_forward(u3_b, q)["out_features"].reshape(-1)
                     mesh["is_on_surface_logits"] = logits
                     mesh["is_on_surface"] = logits > 0
                 mesh.pop("ggm", None)

@@ -250,6 +250,10 @@ int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp,
 
 /* min / max of a float array (device result [2]); level-range check of skimage marching_cubes. */
 int gn_minmax(const float *x, int64_t n, float *out2, void *stream);
+/* the same for `batch` volumes of one shape in one set of launches (one volume per blockIdx.y): vol / out [batch][n0][n1][n2],
+ * tmp [2][batch][n0][n1][n2]; x [batch][n] (n % 4 == 0), out2 [batch][2].  What predict.py:160-181 does garment by garment. */
+int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream);
+int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2, void *stream);
 
 /* Lewiner marching cubes (MC33).  replaces skimage.measure.marching_cubes(method='lewiner') -- predict.py:172-177.
  * gn_mc33_workspace_bytes: bytes of `ws` for a volume of n0*n1*n2.
@@ -260,11 +264,19 @@ size_t gn_mc33_workspace_bytes(int n0, int n1, int n2);
 int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
             int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev,
             void *stream);
+/* `batch` volumes of one shape at one level in one set of launches: vol [batch][n0][n1][n2], verts / normals [batch][cap_v][3], faces
+ * [batch][cap_f][3], values [batch][cap_v], counts_dev [batch][2]; every volume's result is what gn_mc33 gives for it alone. */
+size_t gn_mc33_batch_workspace_bytes(int batch, int n0, int n1, int n2);
+int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                  int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream);
 
 /* out[i] = vol[(uint32)(verts[i]/spacing)] (float64 division, truncation) -- predict.py:179-181.
  * verts_vox: float32 voxel-unit vertices as produced by gn_mc33; spacing applied in fp64 as numpy does. */
 int gn_gather_nn(const float *vol, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
                  float *out, void *stream);
+/* batched: vol [batch][n0][n1][n2], verts_vox [batch][nv][3] (nv rows per volume, padded), out [batch][nv] */
+int gn_gather_nn_batch(const float *vol, int batch, int n0, int n1, int n2, const float *verts_vox, int64_t nv, double spacing,
+                       float *out, void *stream);
 
 /* verts_out[i] = (float)((double)verts_vox[i] * spacing): the float32 query points predict.py:184 feeds to the
  * surface decoder (mc_verts.astype(np.float32)). */

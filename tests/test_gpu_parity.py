@@ -273,15 +273,46 @@ def test_batched_isosurface_tail_equals_per_garment():
     noise = torch.rand(3, 24, 24, 24, generator=torch.Generator().manual_seed(4)) * 0.05
     vols = (base[None] + noise).to(DEV)
     vols[1] = vols[1] * 0.2                          # range [0, ~0.21]: level 0.5 is outside
-    for use_graphs in (True, False, True):           # graph capture, plain launches, graph replay from the cache
-        MCU.USE_ISO_GRAPHS = use_graphs
-        batch = MCU.wnf_batch_to_meshes_gpu(vols, 0.5, 0.5, "ascent")
-        assert isinstance(batch[1], ValueError)
-        for b in (0, 2):
-            one = MCU.wnf_to_mesh_gpu(vols[b], 0.5, 0.5, "ascent")
-            for k in one:
-                assert torch.equal(one[k], batch[b][k]), (use_graphs, k)
-    MCU.USE_ISO_GRAPHS = True
+    saved = MCU.ISO_BATCHED
+    try:
+        # one set of launches for the batch (gn_*_batch, the default); per-garment slot graphs: capture, plain launches, replay from the cache
+        for batched, use_graphs in ((True, True), (False, True), (False, False), (False, True)):
+            MCU.ISO_BATCHED, MCU.USE_ISO_GRAPHS = batched, use_graphs
+            batch = MCU.wnf_batch_to_meshes_gpu(vols, 0.5, 0.5, "ascent")
+            assert isinstance(batch[1], ValueError)
+            for b in (0, 2):
+                one = MCU.wnf_to_mesh_gpu(vols[b], 0.5, 0.5, "ascent")
+                for k in one:
+                    assert torch.equal(one[k], batch[b][k]), (batched, use_graphs, k)
+    finally:
+        MCU.USE_ISO_GRAPHS, MCU.ISO_BATCHED = True, saved
+
+
+@pytest.mark.parametrize("Q,B", [(32, 5), (20, 3), (128, 2)])
+def test_batched_iso_operators_equal_single_volume_calls(Q, B):
+    """gn_ggm3d_batch / gn_minmax_batch / gn_mc33_batch (a volume per blockIdx.y) against the one-volume entry points, bit for bit:
+    shells of different radii (different vertex / face counts per volume), one volume without any surface, one noisy volume"""
+    g = torch.Generator().manual_seed(Q + B)
+    base = torch.from_numpy(S.shell_volume(Q)).float()
+    vols = torch.stack([base * (0.6 + 0.2 * b) + 0.02 * b * torch.rand(Q, Q, Q, generator=g) for b in range(B)])
+    vols[1] = 0.1                                                       # constant: no cell straddles the level
+    vols = vols.to(DEV)
+    cap_v, cap_f = 6 * Q * Q, 12 * Q * Q + 64
+    ggm = ops.ggm3d_batch(vols, 0.5)
+    mm = ops.minmax_batch(vols)
+    verts, faces, normals, values, counts = ops.mc33_batch(vols, 0.5, cap_v, cap_f)
+    cnt = counts.cpu().numpy()
+    assert cnt[1].tolist() == [0, 0] and len({int(c) for c in cnt[:, 0]}) >= 2
+    for b in range(B):
+        assert torch.equal(ggm[b], ops.ggm3d(vols[b].contiguous(), 0.5))
+        assert torch.equal(mm[b], ops.minmax(vols[b].contiguous()))
+        v1, f1, n1, a1, c1 = ops.mc33(vols[b].contiguous(), 0.5, cap_v, cap_f)
+        assert torch.equal(counts[b], c1)
+        nv, nf = int(cnt[b, 0]), int(cnt[b, 1])
+        assert nv <= cap_v and nf <= cap_f
+        assert torch.equal(verts[b, :nv], v1[:nv]) and torch.equal(faces[b, :nf], f1[:nf])
+        assert torch.equal(normals[b, :nv], n1[:nv]) and torch.equal(values[b, :nv], a1[:nv])
+    assert ops.mc33_batch(vols[:0], 0.5, 8, 8)[4].shape == (0, 2)
 
 
 def test_degenerate_sizes():
