@@ -478,9 +478,16 @@ def main():
             if auto_level[0]:
                 mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
                 lvl = 0.5 * (float(mm[0]) + float(mm[1]))
-            for b_, mesh in enumerate(mcu.wnf_batch_to_meshes_gpu(wnf_all, lvl, 0.5, "ascent")):
-                if isinstance(mesh, dict):
-                    model.surface_decoder_forward(u3.select(b_, b_ + 1), mesh["verts_f32"].view(1, -1, 3))
+            job = mcu.IsoBatchJob(args.volume_size, lvl, 0.5, "ascent")          # what predict_batch does after the lattice
+            job.enqueue(wnf_all)
+            meshes = job.finish()
+            q_all = job.padded_queries()
+            if q_all is not None:
+                model.surface_decoder_forward(u3, q_all)
+            else:
+                for b_, mesh in enumerate(meshes):
+                    if isinstance(mesh, dict):
+                        model.surface_decoder_forward(u3.select(b_, b_ + 1), mesh["verts_f32"].view(1, -1, 3))
             ev[4].record()
         torch.cuda.synchronize()
         names = ("pointnet2_forward", "unet3d_forward (gridding + UNet)", "volume_lattice_forward (sampler + decoder)", "GGM + MC33 + surface decode")
