@@ -102,26 +102,33 @@ __device__ __forceinline__ int wave_min_i(int v) {
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int PPT, bool LDS_POS>
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
-                                                         const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ start_idx,
-                                                         int32_t *__restrict__ out_idx) {
+// THREADS = 256 (one wave per SIMD, up to 24 points per thread) for clouds of up to 6144 points: a step costs what its instructions
+// cost in issue slots -- the min-update is the same work however it is spread, but the arg-max reduction (2 x 6 DPP steps + the
+// cross-wave exchange, ~60 instructions per wave) is paid once per wave: 4 waves per SIMD spent as long in it as in the update.
+// The update itself runs on point PAIRS in packed fp32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, half the issue slots).
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+template <int PPT, bool LDS_POS, int THREADS>
+__global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
+                                                      const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ start_idx,
+                                                      int32_t *__restrict__ out_idx) {
+    constexpr int WAVES = THREADS / 64;
+    static_assert(PPT == 1 || PPT % 2 == 0, "points are updated in pairs");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const int s = ptr[b], n = ptr[b + 1] - s;
     const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
     if (n <= 0 || m <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *pv = smem;                       // [2][FPS_WAVES] partial values
-    int *pi = (int *)(smem + 2 * FPS_WAVES);  // [2][FPS_WAVES] partial indices
-    float *lx = smem + 4 * FPS_WAVES;       // SoA positions (LDS_POS only)
+    float *pv = smem;                       // [2][WAVES] partial values
+    int *pi = (int *)(smem + 2 * WAVES);    // [2][WAVES] partial indices
+    float *lx = smem + 4 * WAVES;           // SoA positions (LDS_POS only)
     float *ly = lx + n, *lz = ly + n;
     const float *gp = pos + 3 * (size_t)s;
 
     float px[PPT], py[PPT], pz[PPT], dd[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        int i = tid + j * FPS_THREADS;
+        int i = tid + j * THREADS;
         if (i < n) {
             px[j] = gp[3 * i]; py[j] = gp[3 * i + 1]; pz[j] = gp[3 * i + 2];
             if (LDS_POS) { lx[i] = px[j]; ly[i] = py[j]; lz[i] = pz[j]; }
@@ -140,24 +147,38 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restric
         else { qx = gp[3 * last]; qy = gp[3 * last + 1]; qz = gp[3 * last + 2]; }
         float bv = -1.f;
         int bi = INT_MAX;
+        if (PPT == 1) {
+            if (tid < n) {
+                float d = fminf(dd[0], gn_sqdist3(px[0], py[0], pz[0], qx, qy, qz));
+                dd[0] = d;
+                if (d > bv) { bv = d; bi = tid; }
+            }
+        } else {
+            const fps_f2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            int i = tid + j * FPS_THREADS;
-            if (i < n) {
-                float d = gn_sqdist3(px[j], py[j], pz[j], qx, qy, qz);
-                d = fminf(dd[j], d);
-                dd[j] = d;
-                if (d > bv) { bv = d; bi = i; }  // ascending i: ties keep the lowest index
+            for (int j = 0; j < PPT; j += 2) {
+                // d = (dx*dx + dy*dy) + dz*dz, fp32, no contraction: gn_sqdist3's operations on two points at a time
+                const fps_f2 dx = (fps_f2){px[j], px[j + 1]} - q2x, dy = (fps_f2){py[j], py[j + 1]} - q2y, dz = (fps_f2){pz[j], pz[j + 1]} - q2z;
+                const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = tid + (j + u) * THREADS;
+                    if (i < n) {
+                        const float d = fminf(dd[j + u], u ? d2.y : d2.x);
+                        dd[j + u] = d;
+                        if (d > bv) { bv = d; bi = i; }  // ascending i: ties keep the lowest index
+                    }
+                }
             }
         }
         const float wv = wave_max_f(bv);
         const int wi = wave_min_i(bv == wv ? bi : INT_MAX);
-        const int par = (k & 1) * FPS_WAVES;
+        const int par = (k & 1) * WAVES;
         if (lane == 0) { pv[par + wave] = wv; pi[par + wave] = wi; }
         __syncthreads();
-        // lanes 0..15 of every wave reduce the 16 partials inside one DPP row
-        float fv = pv[par + (lane & (FPS_WAVES - 1))];
-        int fi = pi[par + (lane & (FPS_WAVES - 1))];
+        // lanes 0..WAVES-1 (replicated over the 16-lane DPP row) of every wave reduce the partials
+        float fv = pv[par + (lane & (WAVES - 1))];
+        int fi = pi[par + (lane & (WAVES - 1))];
         const float gv = row_max_f(fv);
         fi = row_min_i(fv == gv ? fi : INT_MAX);
         last = __builtin_amdgcn_readfirstlane(fi);
@@ -172,19 +193,35 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
     const int n = max_points_per_example;
     GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
     const bool lds_pos = n <= 8192;
-    size_t sh = sizeof(float) * 4 * FPS_WAVES + (lds_pos ? sizeof(float) * 3 * (size_t)n : 0);
-    int ppt = (int)gn_cdiv(n, FPS_THREADS);
-#define FPS_LAUNCH(P, L)                                                                                        \
+    const char *fenv = getenv("GARMENTNETS_FPS_THREADS");                     // dev A/B: 256 / 512 / 1024
+    const int want = fenv ? atoi(fenv) : 512;
+    const bool small = n <= 12 * 512 && want != 1024;
+    const int threads = small ? (want == 256 ? 256 : 512) : FPS_THREADS;
+    size_t sh = sizeof(float) * 4 * (threads / 64) + (lds_pos ? sizeof(float) * 3 * (size_t)n : 0);
+    int ppt = (int)gn_cdiv(n, threads);
+#define FPS_LAUNCH(P, L, T)                                                                                     \
     do {                                                                                                        \
-        GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
-        hipLaunchKernelGGL((fps_kernel<P, L>), dim3(B), dim3(FPS_THREADS), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
+        GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
+        hipLaunchKernelGGL((fps_kernel<P, L, T>), dim3(B), dim3(T), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
     } while (0)
-    if (ppt <= 1) FPS_LAUNCH(1, true);
-    else if (ppt <= 2) FPS_LAUNCH(2, true);
-    else if (ppt <= 4) FPS_LAUNCH(4, true);
-    else if (ppt <= 6) FPS_LAUNCH(6, true);
-    else if (ppt <= 8) FPS_LAUNCH(8, true);
-    else FPS_LAUNCH(16, false);
+    if (small && threads == 256) {
+        if (ppt <= 4) FPS_LAUNCH(4, true, 256);
+        else if (ppt <= 8) FPS_LAUNCH(8, true, 256);
+        else if (ppt <= 12) FPS_LAUNCH(12, true, 256);
+        else if (ppt <= 16) FPS_LAUNCH(16, true, 256);
+        else FPS_LAUNCH(24, true, 256);
+    } else if (small) {
+        if (ppt <= 2) FPS_LAUNCH(2, true, 512);
+        else if (ppt <= 4) FPS_LAUNCH(4, true, 512);
+        else if (ppt <= 6) FPS_LAUNCH(6, true, 512);
+        else if (ppt <= 8) FPS_LAUNCH(8, true, 512);
+        else FPS_LAUNCH(12, true, 512);
+    } else if (ppt <= 1) FPS_LAUNCH(1, true, FPS_THREADS);
+    else if (ppt <= 2) FPS_LAUNCH(2, true, FPS_THREADS);
+    else if (ppt <= 4) FPS_LAUNCH(4, true, FPS_THREADS);
+    else if (ppt <= 6) FPS_LAUNCH(6, true, FPS_THREADS);
+    else if (ppt <= 8) FPS_LAUNCH(8, true, FPS_THREADS);
+    else FPS_LAUNCH(16, false, FPS_THREADS);
 #undef FPS_LAUNCH
     GN_LAUNCH_CHECK("gn_fps");
     return GN_OK;
