@@ -21,16 +21,23 @@ timings (RCCL).  Rank 0 prints ONE JSON line:
                         labelled with the kernel variant the C ABI reports having launched (gn_last_kernel), achieved = algorithmic
                         FLOPs (54*Cin*Cout per voxel) / time; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
                         of this same command (profiles/, `traffic_source`), only when the workload is the profiled one
-  occupancy_aware       the same K steps with the library's default occupancy-aware first UNet convolution (exact: bit-identical outputs,
-                        tests/test_gpu_parity.py::test_sparse_first_conv_is_bit_identical_to_dense) on (a) the same synthetic clouds -- whose
-                        predicted NOCS coordinates collapse into a handful of cells under seeded random weights, so this is a best case --
-                        and (b) clouds whose NOCS coordinates are the garment's own normalised, 64-bin quantised positions (the
-                        occupancy a trained PointNet++ produces: thousands of cells), with the dense figure for (b) next to it.  The
-                        HEADLINE value is measured with the occupancy-aware path switched OFF: every tile goes through the matrix cores
-                        and the number does not depend on where the points fall
+  occupancy_aware       the same K steps with the library's default occupancy-aware first two UNet convolutions (exact: bit-identical outputs,
+                        tests/test_gpu_parity.py::test_sparse_first_conv_is_bit_identical_to_dense).  The HEADLINE value is measured with
+                        that path switched OFF: every tile goes through the matrix cores and the number does not depend on where the points fall
+  hbm_members           the HBM-bound members of the path (zero-fill, scatter, max-pool, lattice sampler, GGM, MC33 stages): HIP-event time,
+                        algorithmic bytes, fraction of 8 TB/s
   validation            untimed: a batch of IDENTICAL garments (PointConv self-loop quirk off) must give the same WNF and mesh in the
                         first and the last slot -- garbage in the upper slots of the benchmark batch cannot go unnoticed
-  cpu_baseline          the CPU oracle (torch-CPU port of the reference path) timed on this host for a bounded sample
+  cpu_baseline          the CPU oracle (torch-CPU port of the reference path) timed on this host on garment 0 OF THE BENCHMARK BATCH; its WNF
+                        volume, NOCS bins and occupied cells are compared with slot 0 of the timed HIP result (oracle_check)
+
+INPUT (--input planted, the default): the seeded global batch of synthetic.synthetic_cloud(colour="position") clouds and the seeded
+synthetic checkpoint with synthetic.plant_nocs_path -- the NOCS head decodes the clouds' colour channels (:= the garment's normalised,
+64-bin quantised positions), so the predicted NOCS coordinates spread over the garment's own shape: ~4900 occupied cells of the 128^3
+grid per garment, the occupancy a trained PointNet++ produces, a well-conditioned input on which the north-star tolerance (1e-4 on the
+WNF against the oracle) is enforced by tests/test_gpu_fullsize.py::test_bench_batch_against_oracle on THIS batch.  --input collapsed:
+rounds 1-2's input (uniform colours, un-planted random weights: every cloud collapses into ~5 cells; GroupNorm over a >99.99 % empty
+volume amplifies rounding ~100x -- a conditioning study, not a headline).
 """
 import argparse
 import json
@@ -63,9 +70,13 @@ def parse():
     ap.add_argument("--grid", type=int, default=128, help="feature-volume edge G (north_star: 128; reference ckpt default: 32)")
     ap.add_argument("--reduce", default="mean", choices=["mean", "max"])
     ap.add_argument("--volume-size", type=int, default=128, help="WNF query volume edge Q")
+    ap.add_argument("--input", default="planted", choices=["planted", "collapsed"],
+                    help="planted (default): position-coloured clouds + the planted NOCS path (realistic occupancy, well conditioned); collapsed: "
+                         "rounds 1-2's degenerate input (conditioning study)")
     ap.add_argument("--conv-mode", default="f16x2", choices=["f16x2", "fp32", "bf16x3", "bf16x2"],
                     help="arithmetic of the 3x3x3 convs of the HEADLINE pass: f16x2 (default; fp32 operands split into two fp16 planes, fp32 "
-                         "accumulation), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (preview quality)")
+                         "accumulation), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (PREVIEW: does not guarantee the 1e-4 WNF tolerance -- "
+                         "0.9-1.2e-4 observed on the G=32 goldens)")
     ap.add_argument("--decode-mode", default="f16x2", choices=["f16x2", "fp32"], help="arithmetic of the decoder MLPs of the headline pass")
     ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
                     help="1 (default): one batch at a time (predict.predict_batch, the reference's loop); 2: every timed pass keeps two batches in "
@@ -169,6 +180,80 @@ class KernelTimer:
         return groups
 
 
+class HbmMembers:
+    """HIP-event brackets around the HBM-bound members of the path (zero-fill, scatter, max-pool, sampler, GGM, min/max,
+    MC33) during ONE untimed step; bytes = ALGORITHMIC bytes of the call (each input / output once), fraction of the 8 TB/s HBM3E peak.
+    mc33 is one C-ABI call that launches classify / scan / vertices+attributes / faces: its stage split comes from
+    gn_mc33_batch_profiled (events between the stages inside the call)."""
+
+    def __init__(self):
+        self.records, self.saved = [], {}
+
+    def _wrap(self, name, nbytes):
+        from garmentnets_amd import ops
+        orig = getattr(ops, name)
+        self.saved[name] = orig
+        me = self
+
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **kw)
+            e1.record()
+            me.records.append((name, float(nbytes(out, *a, **kw)), e0, e1))
+            return out
+        setattr(ops, name, timed)
+
+    def install(self):
+        nb = lambda t: t.numel() * t.element_size()
+        self._wrap("zeroed_volume", lambda out, *a, **k: nb(out[0]) + nb(out[1]))
+        self._wrap("grid_scatter", lambda out, src, flat, *a, **k: 2 * nb(src) + nb(flat))
+        self._wrap("maxpool3d_2", lambda out, x, *a, **k: nb(x) + nb(out[0] if isinstance(out, tuple) else out))
+
+        def samp(out, vol_b, query=None, Q=0, m0=0, M=None, **k):
+            rows = query.shape[0] if query is not None else M
+            frac = 1.0 if query is not None or not Q else rows / float(Q) ** 3
+            return rows * vol_b.shape[-1] * 4 + frac * nb(vol_b)
+        self._wrap("trilinear_sample", samp)
+        self._wrap("ggm3d_batch", lambda out, vols, *a, **k: 2 * nb(vols))
+        self._wrap("minmax_batch", lambda out, vols, *a, **k: nb(vols))
+        self._wrap("mc33_batch", lambda out, vols, *a, **k: nb(vols))          # + V * 28 + F * 12, added in summary()
+        self._wrap("gather_nn_batch", lambda out, vols, verts, *a, **k: nb(verts) + nb(out))
+
+    def uninstall(self):
+        from garmentnets_amd import ops
+        for k, v in self.saved.items():
+            setattr(ops, k, v)
+        self.saved = {}
+
+    def reset(self):
+        self.records = []
+
+    def summary(self, wnf_all, level):
+        from garmentnets_amd import ops
+        groups = {}
+        for name, byts, e0, e1 in self.records:
+            g = groups.setdefault(name, dict(bytes=0.0, ms=0.0, calls=0))
+            g["bytes"] += byts
+            g["ms"] += e0.elapsed_time(e1)
+            g["calls"] += 1
+        out = {}
+        for name, g in groups.items():
+            gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
+            out[name] = {"calls": g["calls"], "ms": g["ms"], "algorithmic_bytes": g["bytes"], "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
+        if hasattr(ops, "mc33_batch_profiled") and wnf_all is not None:
+            st = ops.mc33_batch_profiled(wnf_all, level)
+            B, Q = wnf_all.shape[0], wnf_all.shape[-1]
+            stages = {}
+            for k, (ms, byts) in st.items():
+                gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                stages[k] = {"ms": ms, "algorithmic_bytes": byts, "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
+            out["mc33_stages"] = stages
+        out["note"] = ("one untimed step; bytes = algorithmic (each input / output of the call once); scatter is atomics / latency-bound by nature "
+                       "(6000 points per garment), zero-fill runs on a side stream beside farthest-point sampling")
+        return out
+
+
 def measured_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs
     of THIS command, corrected as profiles/*_fetch_calibration.txt documents; tools/pmc_summary.py) -- only quoted when the workload is
@@ -228,8 +313,22 @@ def points_roofline(groups):
     return rl
 
 
-def cpu_baseline(args, hp, sd):
-    """The oracle (a torch-CPU port of the reference path: 'port') on this host's cores, bounded sample."""
+def bench_inputs(batch, points, grid, reduce, input_kind, rank=0, world=1):
+    """the benchmark's model inputs: (hparams, state dict, this rank's shard of the seeded global batch on the host, (lo, hi)).
+    tests/test_gpu_fullsize.py::test_bench_batch_against_oracle calls this to check THE batch the number is quoted on."""
+    from garmentnets_amd import parallel, synthetic as S
+    planted = input_kind == "planted"
+    hp = S.default_hparams(grid=grid, reduce_method=reduce)
+    sd = S.synthetic_state_dict(hp, 0, planted_nocs=planted)
+    shard, span = parallel.shard_batch(batch * world, points, CLOUD_SEED, rank, world, colour="position" if planted else "uniform")
+    return hp, sd, shard, span
+
+
+def cpu_baseline(args, hp, sd, shard, probe):
+    """The oracle (a torch-CPU port of the reference path: 'port') on this host's cores, timed on garment 0 of the benchmark batch
+    (PointConv's self-loop quirk links centre i to point i of the batch: for garment 0 that is the garment itself, so its result alone
+    IS its result in the batch).  -> (cpu_baseline dict, oracle_check dict or None): the oracle's result for that garment against slot
+    0 of the HIP path's (probe: tensors kept from an untimed step)"""
     from garmentnets_amd import synthetic as S
     from oracle import pipeline as P
     ncpu = os.cpu_count() or 1
@@ -251,24 +350,43 @@ def cpu_baseline(args, hp, sd):
     torch.set_num_threads(cores)
     n = args.cpu_baseline_garments
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    npts = args.points
+    x, pos, batch = shard.x[:n * npts].clone(), shard.pos[:n * npts].clone(), shard.batch[:n * npts].clone()
+    check = None
     if args.workload == "pointnet2":
         n = max(n, 4)
-        x, pos, batch = S.synthetic_cloud(n, args.points, seed=12345)
+        x, pos, batch = shard.x[:n * npts].clone(), shard.pos[:n * npts].clone(), shard.batch[:n * npts].clone()
         with torch.no_grad():
-            P.pointnet2_forward(sd_cpu, hp, x[:args.points], pos[:args.points], batch[:args.points])
+            P.pointnet2_forward(sd_cpu, hp, x[:npts], pos[:npts], batch[:npts])
             t0 = time.time()
-            P.pointnet2_forward(sd_cpu, hp, x, pos, batch)
+            ref = P.pointnet2_forward(sd_cpu, hp, x, pos, batch)
             dt = time.time() - t0
-        what = f"{n} garments, PointNet2NOCS forward + NOCS post-processing (N={args.points})"
+        what = f"garments 0..{n - 1} of the benchmark batch, PointNet2NOCS forward + NOCS post-processing (N={npts})"
+        if probe is not None:
+            check = {"garment": 0, "nocs_bins_equal": bool(torch.equal(ref["nocs_data"]["nocs_bin_idx"][:npts], probe["bins0"])),
+                     "features_max_abs_err": float((ref["per_point_features"][:npts] - probe["feat0"]).abs().max())}
+            check["ok"] = check["nocs_bins_equal"] and check["features_max_abs_err"] <= 1e-4
     else:
-        x, pos, batch = S.synthetic_cloud(n, args.points, seed=12345)
+        level = probe["level0"] if probe is not None else 0.5
         t0 = time.time()
-        P.predict(sd_cpu, hp, x, pos, batch, Q=args.volume_size, level=0.5, sigma=0.5, auto_level=True)
+        ref = P.predict(sd_cpu, hp, x, pos, batch, Q=args.volume_size, level=level, sigma=0.5, auto_level=False)
         dt = time.time() - t0
-        what = f"{n} garment(s) of the same workload (N={args.points}, G={args.grid} {args.reduce}, Q={args.volume_size})"
-    return {"value": n / dt, "unit": "garments/s", "cores": cores, "kind": "port",
+        what = f"garment(s) 0..{n - 1} of the benchmark batch (N={npts}, G={args.grid} {args.reduce}, Q={args.volume_size})"
+        if probe is not None:
+            g0 = ref["garments"][0]
+            occ_ref = (ref["in_feature_volume"][0] != 0).any(dim=0)
+            wnf_err = float(np.abs(g0["wnf_volume"] - probe["wnf0"].numpy()).max())
+            check = {"garment": 0, "what": "oracle/pipeline.py on garment 0 of the benchmark batch vs slot 0 of the HIP path (the arithmetic of the headline pass)",
+                     "nocs_bins_equal": bool(torch.equal(ref["pointnet2_result"]["nocs_data"]["nocs_bin_idx"][:npts], probe["bins0"])),
+                     "occupied_cells": int(occ_ref.sum()), "occupied_cells_equal": bool(torch.equal(occ_ref, probe["occ0"])),
+                     "wnf_max_abs_err": wnf_err, "wnf_tolerance": 1e-4, "iso_level": level,
+                     "oracle_mesh": {"verts": int(len(g0["verts"])) if "verts" in g0 else None, "faces": int(len(g0["faces"])) if "faces" in g0 else None},
+                     "hip_mesh": {"verts": probe["verts0"], "faces": probe["faces0"]}}
+            check["ok"] = check["nocs_bins_equal"] and check["occupied_cells_equal"] and wnf_err <= 1e-4
+    base = {"value": n / dt, "unit": "garments/s", "cores": cores, "kind": "port",
             "sample": f"{what}, oracle/pipeline.py on torch-CPU fp32 with {cores} of {ncpu} hardware threads (fastest of a short sweep; fps / ball "
                       f"query / kNN / GGM / marching cubes single-threaded C as in the reference), {dt:.1f} s"}
+    return base, check
 
 
 def validate(model, args, dev, auto_level):
@@ -282,7 +400,7 @@ def validate(model, args, dev, auto_level):
     saved = (pn.sa1_module.conv.add_self_loops, pn.sa2_module.conv.add_self_loops)
     pn.sa1_module.conv.add_self_loops = pn.sa2_module.conv.add_self_loops = False
     try:
-        x, pos, _ = S.synthetic_cloud(1, n, seed=4242)
+        x, pos, _ = S.synthetic_cloud(1, n, seed=4242, colour="position" if args.input == "planted" else "uniform")
         data = Batch(sizes=[n] * B, x=x.repeat(B, 1), pos=pos.repeat(B, 1), batch=torch.arange(B).repeat_interleave(n)).to(dev)
         if args.workload == "pointnet2":
             with torch.no_grad():
@@ -312,7 +430,7 @@ def main():
     rank, local_rank, world = parallel.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    # (GARMENTNETS_DIST_BACKEND=gloo: control-flow smoke test of the N > 1 path on a box with fewer GPUs than ranks -- ranks share devices)
+    # (GARMENTNETS_DIST_BACKEND=gloo: the N > 1 path on a box with fewer GPUs than ranks -- ranks share devices; tests/test_gpu_api.py)
     backend = os.environ.get("GARMENTNETS_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -320,19 +438,18 @@ def main():
     parallel.init(backend=backend, device=dev)     # "nccl" is RCCL on ROCm; no-op for one process
     metrics_dev = dev if backend == "nccl" else "cpu"
 
-    from garmentnets_amd import ops, synthetic as S
+    from garmentnets_amd import ops
+    from garmentnets_amd.arith import Arith
     from garmentnets_amd.batch import Batch
     from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
     from garmentnets_amd.predict import PredictJob, predict_batch, to_host
 
-    hp = S.default_hparams(grid=args.grid, reduce_method=args.reduce)
-    sd = S.synthetic_state_dict(hp, 0)
+    # the global batch of batch x world garments (one seed), sharded contiguously: this rank owns garments [lo, hi)
+    global_batch = args.batch * world
+    hp, sd, shard, (lo, hi) = bench_inputs(args.batch, args.points, args.grid, args.reduce, args.input, rank, world)
     model = ConvImplicitWNFPipeline(**hp)
     model.load_state_dict(sd)
     model = model.to(dev).eval().requires_grad_(False)
-    # the global batch of batch x world garments (one seed), sharded contiguously: this rank owns garments [lo, hi)
-    global_batch = args.batch * world
-    shard, (lo, hi) = parallel.shard_batch(global_batch, args.points, CLOUD_SEED, rank, world)
     host_data = Batch(sizes=shard.sizes, x=shard.x.pin_memory(), pos=shard.pos.pin_memory(), batch=shard.batch.pin_memory())
     data = host_data.to(dev)                         # resident in HBM before timing
     timer = KernelTimer()
@@ -340,9 +457,10 @@ def main():
         timer.install_points()
     else:
         timer.install_conv()
-    import garmentnets_amd.components.unet3d as u
-    u.ops = ops
 
+    # the model's arithmetic is a per-model immutable value (garmentnets_amd/arith.py): each pass installs its own
+    headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False)    # dense, occupancy-independent
+    model.arith = headline
     auto_level = [False]
 
     def step(d=data):
@@ -372,7 +490,7 @@ def main():
         prev = None
         for k in range(n):
             d = host_data.to(dev, non_blocking=True) if fn is step_host_io else data
-            job = PredictJob(model, d, args.volume_size, 0.5, 0.5, "ascent", bank=1 + (k & 1))
+            job = PredictJob(model, d, args.volume_size, 0.5, 0.5, "ascent")
             if prev is not None:
                 res = prev.finish(host=fn is step_host_io)
             prev = job
@@ -396,33 +514,42 @@ def main():
         timer.enabled = False
         return dt, res, timer.summary()
 
-    def set_modes(conv, decode):
-        ops.CONV_MODE = ops.CONV_MODE_NAMES[conv]
-        ops.DECODE_MODE = decode
-
-    set_modes(args.conv_mode, args.decode_mode)
-    ops.SPARSE_FIRST_CONV = False                    # headline / strict / host-io passes: dense, occupancy-independent
     # synthetic weights: use the reference's fixed level 0.5 if every garment's WNF straddles it, else the mid level
     if args.workload == "full":
-        probe = step()
-        if any(bool(torch.isnan(r["verts"]).any()) for r in probe):
+        probe_res = step()
+        if any(bool(torch.isnan(r["verts"]).any()) for r in probe_res):
             auto_level[0] = True
-        del probe
+        del probe_res
     pipelined[0] = args.workload == "full" and args.pipeline_depth == 2 and not auto_level[0]
     dt, res, groups = timed(step, args.steps, max(2, args.warmup - 1) if pipelined[0] else max(0, args.warmup - (1 if args.workload == "full" else 0)))
     verts_total = None
+    checksums = []                                   # per local garment: fp64 sum of its WNF volume (full) / logits (pointnet2), last timed step
+    probe = None                                     # slot 0 of the timed result, kept for the oracle check of the cpu_baseline leg
     if args.workload == "full":
+        checksums = torch.stack([r["wnf_volume"].double().sum() for r in res]).cpu().tolist()
         verts_total = sum(int(r["verts"].shape[0]) for r in res)
         assert not any(bool(torch.isnan(r["verts"]).any()) for r in res), "marching cubes produced a placeholder mesh"
+        if rank == 0:
+            r0 = res[0]
+            w0 = r0["wnf_volume"]
+            level0 = 0.5 * (float(w0.min()) + float(w0.max())) if auto_level[0] else 0.5
+            bins0 = torch.round(r0["pred_nocs"] * (model.pointnet2_nocs.nocs_bins - 1)).to(torch.int64).cpu()
+            probe = dict(wnf0=w0.cpu(), level0=level0, bins0=bins0, verts0=int(r0["verts"].shape[0]), faces0=int(r0["faces"].shape[0]))
+    else:
+        checksums = res["per_point_logits"].double().view(hi - lo, -1).sum(dim=1).cpu().tolist()
+    if args.workload != "full" and rank == 0:
+        n = args.points
+        bins0, _, _ = ops.nocs_head(res["per_point_logits"][:n].contiguous(), model.pointnet2_nocs.nocs_bins)
+        probe = dict(bins0=bins0.cpu(), feat0=res["per_point_features"][:n].cpu())
     del res
 
     strict = None
     if not args.no_strict_pass and (args.conv_mode, args.decode_mode) != ("fp32", "fp32") and args.workload == "full":
-        set_modes("fp32", "fp32")
+        model.arith = headline.strict_fp32()
         dt_s, res_s, groups_s = timed(step, args.steps, 1)
         del res_s
         strict = (dt_s, groups_s)
-        set_modes(args.conv_mode, args.decode_mode)
+        model.arith = headline
     hostio = None
     if not args.no_host_io_pass:
         dt_h, res_h, _ = timed(step_host_io, args.steps, 1)
@@ -431,68 +558,62 @@ def main():
 
     occupancy = None
     if not args.no_occupancy_pass and args.workload == "full" and args.conv_mode in ("f16x2", "bf16x2"):
-        def tiles_seen():
-            with torch.no_grad():
-                vin = model.volume_agg(model.pointnet2_forward(data)["nocs_data"])
-                fl = ops.grid_tile_flags(vin._gn_flat, hi - lo, (args.grid,) * 3)
-                occ = int((vin.permute(0, 2, 3, 4, 1) != 0).any(dim=-1).sum())
-            return {"occupied_cells_per_garment": occ / (hi - lo), "active_tile_fraction": float(fl.float().mean())}
-
-        occupancy = {}
-        ops.SPARSE_FIRST_CONV = True
+        model.arith = headline.replace(sparse_first_conv=True)
         dt_a, _, _ = timed(step, args.steps, 1)
-        occupancy["synthetic_clouds"] = dict(tiles_seen(), seconds=dt_a)
-        orig_p2 = model.pointnet2_forward
+        model.arith = headline
+        with torch.no_grad():
+            vin = model.volume_agg(model.pointnet2_forward(data)["nocs_data"])
+            fl = ops.grid_tile_flags(vin._gn_flat, hi - lo, (args.grid,) * 3)
+            occ = int((vin.permute(0, 2, 3, 4, 1) != 0).any(dim=-1).sum())
+            if probe is not None:
+                probe["occ0"] = (vin[0] != 0).any(dim=0).cpu()
+            del vin
+        occupancy = {"seconds": dt_a, "occupied_cells_per_garment": occ / (hi - lo), "active_tile_fraction": float(fl.float().mean())}
+    elif probe is not None and args.workload == "full":
+        with torch.no_grad():
+            vin = model.volume_agg(model.pointnet2_forward(data)["nocs_data"])
+            probe["occ0"] = (vin[0] != 0).any(dim=0).cpu()
+            del vin
 
-        def spread_nocs(d):                          # NOCS := the garment's own normalised, 64-bin quantised positions (bench input, not the network's prediction)
-            res = orig_p2(d)
-            p3 = d.pos.view(hi - lo, args.points, 3)
-            mn, mx = p3.min(dim=1, keepdim=True)[0], p3.max(dim=1, keepdim=True)[0]
-            res["nocs_data"].pos = (torch.round((0.1 + 0.8 * (p3 - mn) / (mx - mn)) * 63) * (1.0 / 63)).view(-1, 3).contiguous()
-            return res
-        model.pointnet2_forward = spread_nocs
-        try:
-            dt_b, _, _ = timed(step, args.steps, 1)
-            occupancy["realistic_occupancy"] = dict(tiles_seen(), seconds=dt_b)
-            ops.SPARSE_FIRST_CONV = False
-            dt_c, _, _ = timed(step, args.steps, 1)
-            occupancy["realistic_occupancy"]["seconds_dense"] = dt_c
-        finally:
-            del model.pointnet2_forward
-            ops.SPARSE_FIRST_CONV = False
-
-    # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods
-    stages_ms = None
+    # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods.  The same
+    # step carries the HIP-event brackets of the HBM-bound members (hbm_members)
+    stages_ms = hbm_members = None
     if rank == 0 and args.workload == "full":
         from garmentnets_amd.common import marching_cubes_util as mcu
+        hbm = HbmMembers()
+        hbm.install()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         with torch.no_grad():
-            ev[0].record()
-            p2 = model.pointnet2_forward(data)
-            ev[1].record()
-            u3 = model.unet3d_forward(p2)
-            ev[2].record()
-            wnf_all = model.volume_lattice_forward(u3, args.volume_size)["pred_volume"]
-            ev[3].record()
-            lvl = 0.5
-            if auto_level[0]:
-                mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
-                lvl = 0.5 * (float(mm[0]) + float(mm[1]))
-            job = mcu.IsoBatchJob(args.volume_size, lvl, 0.5, "ascent")          # what predict_batch does after the lattice
-            job.enqueue(wnf_all)
-            meshes = job.finish()
-            q_all = job.padded_queries()
-            if q_all is not None:
-                model.surface_decoder_forward(u3, q_all)
-            else:
-                for b_, mesh in enumerate(meshes):
-                    if isinstance(mesh, dict):
-                        model.surface_decoder_forward(u3.select(b_, b_ + 1), mesh["verts_f32"].view(1, -1, 3))
-            ev[4].record()
-        torch.cuda.synchronize()
+            for rep in range(2):                      # the second repetition is the one reported (allocator and caches warm)
+                hbm.reset()
+                ev[0].record()
+                p2 = model.pointnet2_forward(data, prefetch_volume=True)
+                ev[1].record()
+                u3 = model.unet3d_forward(p2)
+                ev[2].record()
+                wnf_all = model.volume_lattice_forward(u3, args.volume_size)["pred_volume"]
+                ev[3].record()
+                lvl = 0.5
+                if auto_level[0]:
+                    mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
+                    lvl = 0.5 * (float(mm[0]) + float(mm[1]))
+                job = mcu.IsoBatchJob(args.volume_size, lvl, 0.5, "ascent")          # what predict_batch does after the lattice
+                job.enqueue(wnf_all)
+                meshes = job.finish()
+                q_all = job.padded_queries()
+                if q_all is not None:
+                    model.surface_decoder_forward(u3, q_all)
+                else:
+                    for b_, mesh in enumerate(meshes):
+                        if isinstance(mesh, dict):
+                            model.surface_decoder_forward(u3.select(b_, b_ + 1), mesh["verts_f32"].view(1, -1, 3))
+                ev[4].record()
+                torch.cuda.synchronize()
+        hbm.uninstall()
         names = ("pointnet2_forward", "unet3d_forward (gridding + UNet)", "volume_lattice_forward (sampler + decoder)", "GGM + MC33 + surface decode")
         stages_ms = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
-        del p2, u3, wnf_all
+        hbm_members = hbm.summary(wnf_all, lvl)
+        del p2, u3, wnf_all, job, meshes
 
     validation = None
     if rank == 0 and not args.no_validate:
@@ -513,9 +634,9 @@ def main():
 
     # the only collective: per-rank (garments, seconds of each timed pass) over RCCL/xGMI
     n_local = (hi - lo) * args.steps
-    occ_t = [occupancy[k].get(f, 0.0) for k, f in (("synthetic_clouds", "seconds"), ("realistic_occupancy", "seconds"), ("realistic_occupancy", "seconds_dense"))] \
-        if occupancy else [0.0, 0.0, 0.0]
-    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0] + occ_t + [in_flight or 0.0], device=metrics_dev)
+    per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0, occupancy["seconds"] if occupancy else 0.0,
+                                        in_flight or 0.0], device=metrics_dev)
+    all_sums = parallel.gather_vector(checksums, device=metrics_dev)
     if rank == 0:
         value, tmax = parallel.aggregate_throughput(per_rank)
         garments = sum(r[0] for r in per_rank)
@@ -524,25 +645,32 @@ def main():
         dtype = "f32" if not split and args.decode_mode == "fp32" else (
             f"f32 ({args.conv_mode} operand split on the 16-bit matrix cores for the 3x3x3 convs" + (" and the decoder MLPs" if args.decode_mode == "f16x2" else "") +
             ", fp32 accumulation; everything else fp32/fp64)" if split else "f32 (f16x2 operand split for the decoder MLPs only)")
+        if args.input == "planted":
+            input_note = ("position-coloured synthetic dress clouds + seeded synthetic checkpoint with the planted NOCS path (synthetic.plant_nocs_path): "
+                          "predicted NOCS spread over the garment's shape, realistic occupancy")
+        else:
+            input_note = "uniform-colour synthetic dress clouds + un-planted seeded random weights: every cloud collapses into a handful of cells (conditioning study)"
         if args.workload == "pointnet2":
             metric = "garments/s PointNet++ NOCS forward (pointnet2_nocs.py:134-166 + NOCS post-processing)"
-            workload = f"PointNet2NOCS forward only, batch={args.batch}/GPU, {args.points}-pt clouds (BASELINE config[1])"
+            workload = f"PointNet2NOCS forward only, batch={args.batch}/GPU, {args.points}-pt clouds (BASELINE config[1]); input: {input_note}"
             dtype = "f32"
             roofline = points_roofline(groups)
         else:
             metric = "garments/s end-to-end predict (PointNet++ -> gridding -> UNet3D -> WNF decode -> marching cubes)"
             workload = (f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, {args.grid}^3 feature volume ({args.reduce}), "
-                        f"{args.volume_size}^3 WNF + GGM + MC33 + surface decode")
+                        f"{args.volume_size}^3 WNF + GGM + MC33 + surface decode; input: {input_note}"
+                        + (f" ({occupancy['occupied_cells_per_garment']:.0f} occupied cells per garment)" if occupancy else ""))
             roofline = conv_roofline(args, groups, args.conv_mode)
         line = {
             "metric": metric, "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "batch_per_gpu": args.batch, "global_batch": global_batch,
+            "config": {"workload": workload, "input": args.input, "batch_per_gpu": args.batch, "global_batch": global_batch,
                        "sharding": f"garments [r*{args.batch}, (r+1)*{args.batch}) of one seeded global batch per rank (parallel.shard_range)",
                        "points": args.points, "grid": args.grid, "reduce": args.reduce,
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level[0] else 0.5,
-                       "weights": "seeded synthetic (reference architecture)", "mesh_verts_per_step": verts_total,
+                       "weights": "seeded synthetic (reference architecture)" + (" + planted NOCS path" if args.input == "planted" else ""),
+                       "encoder_convs": "dense (occupancy-aware launch OFF for the headline)", "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
             "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh); K batches "
                             "begun and finished between the two barriers" + (
@@ -550,16 +678,19 @@ def main():
                                 "slices, surface decode) is finished (predict.PredictJob; bit-equal results: tests/test_gpu_api.py)" if pipelined[0] else ", one at a time"),
             "pipeline_depth": 2 if pipelined[0] else 1,
             "rccl_ranks_seen": len(per_rank),
+            "dist_backend": backend if world > 1 else None,
+            "garment_checksums": [c for r in all_sums for c in r],      # global garment order (rank-major): fp64 sum of each result
             "stages_ms": stages_ms,
             "roofline": roofline,
         }
+        if hbm_members is not None:
+            line["hbm_members"] = hbm_members
         if in_flight is not None:
-            tq = max(r[7] for r in per_rank)
+            tq = max(r[5] for r in per_rank)
             line["two_in_flight"] = {"value": garments / tq, "unit": "garments/s", "ms_per_step": 1e3 * tq / args.steps, "steps": args.steps,
                                      "what": "the same K batches through predict.PredictJob: batch k+1's PointNet++ / UNet / lattice is queued before batch "
                                              "k's tail (vertex counts to the host, mesh slices, surface decode; on its own stream) is finished.  Bit-equal "
-                                             "results (tests/test_gpu_api.py); the step is matrix-core / power bound, so hiding the latency-bound tail buys "
-                                             "little"}
+                                             "results (tests/test_gpu_api.py)"}
         if strict:
             ts = max(r[2] for r in per_rank)
             line["strict_fp32"] = {"value": garments / ts, "unit": "garments/s", "ms_per_step": 1e3 * ts / args.steps, "steps": args.steps,
@@ -572,24 +703,23 @@ def main():
                                                 "gradient magnitude / warp field of every garment (predict.to_host)" if args.workload == "full" else
                                                 "pinned-host -> HBM copy of the clouds, the step, device -> host copy of every result tensor"}
         if occupancy:
-            def rate(slot):
-                t = max(r[slot] for r in per_rank)
-                return {"value": garments / t, "unit": "garments/s", "ms_per_step": 1e3 * t / args.steps}
+            to = max(r[4] for r in per_rank)
             line["occupancy_aware"] = {
-                "what": "first UNet convolution visits only the output tiles that can see an occupied cell (exact, bit-identical to the dense launch; the "
-                        "library default, switched off for the headline value)",
-                "synthetic_clouds": dict(rate(4), **{k: v for k, v in occupancy["synthetic_clouds"].items() if k != "seconds"},
-                                         note="seeded random weights collapse every cloud's NOCS prediction into a handful of cells: best case, not representative"),
-                "realistic_occupancy": dict(rate(5), dense=rate(6), **{k: v for k, v in occupancy["realistic_occupancy"].items() if not k.startswith("seconds")},
-                                            note="NOCS coordinates := the garment's own normalised, 64-bin quantised point positions (bench input construction), "
-                                                 "i.e. the cell occupancy a trained PointNet++ produces")}
+                "value": garments / to, "unit": "garments/s", "ms_per_step": 1e3 * to / args.steps,
+                "what": "the library default: the first two UNet convolutions visit only the output tiles that can see an occupied cell (exact, bit-identical "
+                        "to the dense launch; switched off for the headline value) -- same input, same K steps",
+                "occupied_cells_per_garment": occupancy["occupied_cells_per_garment"], "active_tile_fraction": occupancy["active_tile_fraction"]}
         if validation is not None:
             line["validation"] = validation
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, hp, sd)
+            line["cpu_baseline"], check = cpu_baseline(args, hp, sd, shard, probe)
+            if check is not None:
+                line["oracle_check"] = check
         print(json.dumps(line))
         if validation is not None and not validation["ok"]:
             raise SystemExit("bench.py: validation failed (identical garments gave different results in slot 0 and the last slot)")
+        if line.get("oracle_check") is not None and not line["oracle_check"]["ok"]:
+            raise SystemExit("bench.py: oracle check failed (slot 0 of the timed result differs from the CPU oracle beyond the tolerance)")
     if world > 1:
         torch.distributed.destroy_process_group()
 

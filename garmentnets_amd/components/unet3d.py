@@ -13,6 +13,7 @@ The torch layers only hold parameters.  Execution is channel-last ([B][D][H][W][
 import torch
 from torch import nn
 
+from .. import arith as AR
 from .. import ops
 from .mlp import PackedModule, pack_wb
 
@@ -38,8 +39,8 @@ class SingleConv(PackedModule, nn.Sequential):
         wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
         return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None):
-        """src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
+    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None, arith=None):
+        """arith: the arith.Arith of this call (None: arith.DEFAULT).  src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
         stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them.
         sparse: occupancy-aware launch (split-operand modes), a dict
             flat      flat cell index of every point gn_grid_scatter scattered into the volume this layer descends from
@@ -47,13 +48,14 @@ class SingleConv(PackedModule, nn.Sequential):
             small_in  (reach 2) the reach-1 layer's output over the 5 x 5 x 5 all-zero volume; this call adds 'small_out', its own
         Only the output tiles that can see an occupied cell (within `reach`) go through the matrix cores; the rest are border-class
         constants taken from a dense launch of this layer over the 5^3 zero volume with the same affine: bit-identical output."""
+        arith = arith or AR.DEFAULT
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None
         if src1 is not None:
             st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
-        if ops.CONV_MODE != ops.CONV_FP32:      # split-operand path on the 16-bit matrix cores (csrc/unet_split.hip)
-            mode = ops.CONV_MODE
+        if arith.conv_mode != ops.CONV_FP32:      # split-operand path on the 16-bit matrix cores (csrc/unet_split.hip)
+            mode = arith.conv_mode
             # fp16 planes: the sample's activations are range-normalised by a power of two (exact, undone in the epilogue)
             a, d, act_inv = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta, with_act_scale=True) \
                 if mode == ops.SPLIT_F16X2 else ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta) + (None,)
@@ -63,7 +65,7 @@ class SingleConv(PackedModule, nn.Sequential):
                 cache.clear()
                 cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
             cout, sp = self.conv.out_channels, {}
-            if (sparse is not None and ops.SPARSE_FIRST_CONV and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
+            if (sparse is not None and arith.sparse_first_conv and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
                     and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]):
                 B, reach = src0.shape[0], int(sparse["reach"])
                 small_in = sparse.get("small_in")
@@ -80,7 +82,7 @@ class SingleConv(PackedModule, nn.Sequential):
                 kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
                 sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
                 sparse["small_out"] = small_out
-            if src1 is not None and ops.POLYPHASE_UPCONV and mode != ops.SPLIT_BF16X3 and src1.shape[-1] <= 384:
+            if src1 is not None and arith.polyphase_upconv and mode != ops.SPLIT_BF16X3 and src1.shape[-1] <= 384:
                 # polyphase form: the nearest-upsampled channels as a 2x2x2-tap convolution per output parity class on the COARSE volume
                 # (8/27 of their MACs, the coarse halo staged once for all classes: csrc/upconv.hip), added in the fine launch's epilogue
                 c0 = src0.shape[-1]
@@ -114,12 +116,12 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None):
+    def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None, arith=None):
         """sparse_flat: src0 is gn_grid_scatter's volume (flat cell index of every scattered point): both convolutions run occupancy-aware"""
         sp1 = dict(flat=sparse_flat, reach=1) if sparse_flat is not None else None
-        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1)
+        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1, arith=arith)
         sp2 = dict(flat=sparse_flat, reach=2, small_in=sp1["small_out"]) if (sp1 is not None and "small_out" in sp1) else None
-        return self.SingleConv2.run(y, None, st, sparse=sp2)
+        return self.SingleConv2.run(y, None, st, sparse=sp2, arith=arith)
 
 
 class Encoder(nn.Module):
@@ -128,7 +130,7 @@ class Encoder(nn.Module):
         self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=True, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, x, stats=None, sparse_flat=None):
+    def run(self, x, stats=None, sparse_flat=None, arith=None):
         if self.pooling is not None:
             sparse_flat = None
             c = x.shape[-1]
@@ -136,7 +138,7 @@ class Encoder(nn.Module):
                 x, stats = ops.maxpool3d_2(x, with_stats=True)
             else:
                 x, stats = ops.maxpool3d_2(x), None
-        return self.basic_module.run(x, None, stats, sparse_flat=sparse_flat)
+        return self.basic_module.run(x, None, stats, sparse_flat=sparse_flat, arith=arith)
 
 
 class Decoder(nn.Module):
@@ -144,9 +146,9 @@ class Decoder(nn.Module):
         super().__init__()
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=False, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, encoder_features, x, stats_skip=None, stats_x=None):
+    def run(self, encoder_features, x, stats_skip=None, stats_x=None, arith=None):
         # cat((encoder_features, upsample_nearest(x)), dim=channel) is never materialised
-        return self.basic_module.run(encoder_features, x, stats_skip, stats_x)
+        return self.basic_module.run(encoder_features, x, stats_skip, stats_x, arith=arith)
 
 
 class FinalConv1x1(PackedModule, nn.Conv3d):
@@ -177,17 +179,18 @@ class Abstract3DUNet(nn.Module):
             Decoder(rf[i] + rf[i + 1], rf[i + 1], conv_layer_order=layer_order, num_groups=num_groups) for i in range(len(rf) - 1)])
         self.final_conv = FinalConv1x1(f_maps[0], out_channels, 1)
         self.final_activation = None
+        self.arith = None        # arithmetic of forward(x) (None: arith.DEFAULT); run() takes it per call
 
-    def run(self, x, stats=None, pre_final=False, return_stats=False, sparse_flat=None):
+    def run(self, x, stats=None, pre_final=False, return_stats=False, sparse_flat=None, arith=None):
         """channel-last in, channel-last out (pre_final: stop before the final 1x1x1 convolution -- it is linear, so the decoders can
         fold it into their first layer and sample the f_maps[0]-channel volume instead: networks/conv_implicit_wnf.py UNetResult).  Every kernel that produces a tensor also emits the per-channel statistics the
         next GroupNorm needs (conv / max-pool epilogues), so no activation is re-read for normalisation."""
         feats = []
         for i, enc in enumerate(self.encoders):
-            x, stats = enc.run(x, stats, sparse_flat=sparse_flat if i == 0 else None)
+            x, stats = enc.run(x, stats, sparse_flat=sparse_flat if i == 0 else None, arith=arith)
             feats.insert(0, (x, stats))
         for dec, (skip, skip_stats) in zip(self.decoders, feats[1:]):
-            x, stats = dec.run(skip, x, skip_stats, stats)
+            x, stats = dec.run(skip, x, skip_stats, stats, arith=arith)
         if pre_final:       # return_stats: + (sum, sumsq, V) of the pre-final volume (the decoders derive their input scale from it)
             return (x, stats) if return_stats else x
         return self.final_conv.run(x)
@@ -195,7 +198,7 @@ class Abstract3DUNet(nn.Module):
     def forward(self, x):
         """x: (B, C, D, H, W) as in the reference; returns (B, C', D, H, W) (a view over channel-last storage)."""
         stats = getattr(x, "_gn_stats", None)
-        return self.run(to_channel_last(x), stats).permute(0, 4, 1, 2, 3)
+        return self.run(to_channel_last(x), stats, arith=self.arith).permute(0, 4, 1, 2, 3)
 
 
 def to_channel_last(x):

@@ -3,8 +3,12 @@
 /root/reference/predict.py:74-84,191-279 writes, per sample, the groups
     samples/<key>/marching_cubes_mesh/{verts,faces,normals,volume_value,volume_gradient_magnitude,warp_field[,is_on_surface,
                                         is_on_surface_logits]}
-    samples/<key>/point_cloud/{pred_nocs,pred_nocs_confidence,pred_nocs_logits,input_points,input_rgb[,gt_nocs]}
-    samples/<key>/misc/{pred_nocs_grip_point,pred_global_nocs_grip_point,pred_global_confidence,global_feature[,gt_nocs_grip_point]}
+    samples/<key>/point_cloud/{pred_nocs,pred_nocs_confidence,pred_nocs_logits,input_points,input_rgb,gt_nocs}
+    samples/<key>/misc/{gt_nocs_grip_point,pred_nocs_grip_point,pred_global_nocs_grip_point,pred_global_confidence,global_feature}
+    samples/<key>/gt_marching_cubes_mesh/   (zarr.copy of the input sample's marching_cube_mesh group: copy_group)
+    samples/<key>/gt_mesh/{cloth_verts (rotated by the augmentation matrix),cloth_nocs_verts,cloth_faces_tri,...}
+    samples/<key>/.zattrs  {scale, gender, sample_id, garment_name, grip_vertex_idx, batch_idx}
+(predict.write_prediction_sample assembles a sample; the gt_* parts exist for dataset samples only),
 each array stored as ONE chunk (chunks == shape) and read back by eval.py through `zarr` (eval.py:58-102,185-257,904-935).
 This writer emits spec-conformant Zarr v2 metadata (`.zgroup`, `.zattrs`, `.zarray`, chunk files "0.0...") with
 `compressor: null` or the stdlib `zlib` codec (`{"id": "zlib", "level": n}`), both readable by any Zarr v2 implementation;
@@ -89,6 +93,16 @@ class Group:
     def keys(self):
         return sorted(d for d in os.listdir(self.path) if not d.startswith("."))
 
+    def __contains__(self, name):
+        path = os.path.join(self.path, *name.strip("/").split("/"))
+        return os.path.exists(os.path.join(path, ".zarray")) or os.path.exists(os.path.join(path, ".zgroup"))
+
+    def arrays(self):
+        """(name, numpy array) of every array directly in this group, sorted by name (zarr's Group.arrays())"""
+        for k in self.keys():
+            if os.path.exists(os.path.join(self.path, k, ".zarray")):
+                yield k, _read_array(os.path.join(self.path, k))
+
     @property
     def attrs(self):
         p = os.path.join(self.path, ".zattrs")
@@ -143,6 +157,17 @@ def open_group(path, create=True):
     if fresh:
         g.put_attrs({"codec_note": CODEC_NOTE})
     return g
+
+
+def copy_group(src_group, dst_parent, name):
+    """zarr.copy(src_group, dst_parent, name=name, if_exists='replace') for directory stores (predict.py:236-239): the source group's
+    metadata and chunk files are copied as they are -- shapes, dtypes, chunking AND codec (Blosc chunks included: nothing is decoded)"""
+    import shutil
+    dst = os.path.join(dst_parent.path, name)
+    if os.path.exists(dst):
+        shutil.rmtree(dst)
+    shutil.copytree(src_group.path, dst)
+    return Group(dst, create=False)
 
 
 def write_sample(samples_group, key, mesh, point_cloud, misc, attrs=None, compressor=("zlib", 1)):

@@ -11,6 +11,7 @@ import os
 import torch
 from torch import nn
 
+from .. import arith as AR
 from .. import ops
 from ..batch import Batch
 from ..components.mlp import MLP, PackedModule, fold_batchnorm
@@ -34,16 +35,18 @@ class VolumeFeatureAggregator(nn.Module):
 
     def prefetch_zero(self, B, device):
         """zero-fill the (B, G, G, G, C) volume of the NEXT forward() on a side stream, now: the fill (17 GB at batch 16, 128^3: 3 ms of
-        pure HBM writes) then runs next to PointNet++'s serial farthest-point sampling (16 workgroups on 256 CUs) instead of after it"""
+        pure HBM writes) then runs next to PointNet++'s serial farthest-point sampling (16 workgroups on 256 CUs) instead of after it.
+        Only callers that WILL run forward() next ask for it (ConvImplicitWNFPipeline.forward, predict._dense_phase) and they call
+        drop_prefetch() on their way out, so the buffer never outlives the step that asked for it."""
         if not PREFETCH_ZERO or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
             return
         C = self.local_nn[-1][0].out_features if self.local_nn is not None else None
         if C is None:
             return
-        dev = torch.device(device)
+        dev = _normalise_device(device)
         pre = self.__dict__.get("_prezero")
         if pre is not None and pre[0] == B and pre[1].device == dev:
-            return                                   # the previous prefetch was never consumed (pointnet2_forward alone in a loop): still zero
+            return                                   # an earlier prefetch of this shape was never consumed: still zero
         if B * int(torch.tensor(self.grid_shape).prod()) * C * 4 < (64 << 20):
             return                                   # small volumes: the in-stream memset costs microseconds
         main = torch.cuda.current_stream(dev)
@@ -57,6 +60,12 @@ class VolumeFeatureAggregator(nn.Module):
             ev.record(side)
         self.__dict__["_prezero"] = (B, vol, cnt, ev)
 
+    def drop_prefetch(self):
+        """release an unconsumed prefetch_zero buffer (17 GB at batch 16, 128^3)"""
+        pre = self.__dict__.pop("_prezero", None)
+        if pre is not None:
+            pre[1].record_stream(torch.cuda.current_stream(pre[1].device))     # filled on the side stream, freed from this one
+
     def forward(self, nocs_data):
         B = nocs_data.num_graphs
         conf = nocs_data.pred_confidence
@@ -67,6 +76,8 @@ class VolumeFeatureAggregator(nn.Module):
             feats = self.local_nn(feats)
         pre = self.__dict__.pop("_prezero", None)
         prezeroed = None
+        if pre is not None and torch.cuda.is_current_stream_capturing():
+            pre = None                                # a captured graph must own its memset: never bake "already zero" into it
         if pre is not None and pre[0] == B and pre[1].shape[-1] == feats.shape[1] and pre[1].device == feats.device:
             torch.cuda.current_stream(feats.device).wait_event(pre[3])
             prezeroed = (pre[1], pre[2])
@@ -75,6 +86,13 @@ class VolumeFeatureAggregator(nn.Module):
         out._gn_stats = stats      # GroupNorm statistics of the (mostly empty) volume, from its occupied cells only
         out._gn_flat = flat        # the occupied cells: the first UNet convolution only visits the tiles that can see one
         return out
+
+
+def _normalise_device(device):
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
 
 
 class UNet3D(nn.Module):
@@ -106,6 +124,7 @@ class ImplicitWNFDecoder(PackedModule):
         self.mlp = MLP(list(nn_channels), batch_norm=batch_norm)
         self.nn_channels = tuple(nn_channels)
         self.out_channels = nn_channels[-1]
+        self.arith = None          # arithmetic of a direct call (None: arith.DEFAULT); the pipeline passes its own per call
 
     def _pack(self):
         ch = self.nn_channels
@@ -118,7 +137,7 @@ class ImplicitWNFDecoder(PackedModule):
             sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
             layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
             raw.append((w, b, sc, sh))
-        # the shipped [128,256,256,out] decoder also gets the split-operand pack (csrc/decode_split.hip, ops.DECODE_MODE)
+        # the shipped [128,256,256,out] decoder also gets the split-operand pack (csrc/decode_split.hip, Arith.decode_mode)
         split = ops.pack_decode_split(raw).to(w.device) if tuple(ch[:3]) == (128, 256, 256) else None
         return tuple(layers) + (split,)
 
@@ -154,12 +173,14 @@ class ImplicitWNFDecoder(PackedModule):
                 cache[key] = tuple(layers) + (split,)
         return cache[key]
 
-    def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None, xscale=None):
+    def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None, xscale=None, arith=None):
         """vol_b [D][H][W][C]: the decoder's own input volume, or (with the folded `layers`) the UNet's pre-final volume;
         xscale: this garment's (s, 1/s) input scale for the split-operand kernel (ops.decoder_input_scale)"""
+        arith = arith or AR.DEFAULT
         M = out.shape[0]
         if layers is None:
             layers = self.packed() if self.fused else None
+        split = layers is not None and layers[3] is not None and arith.decode_mode == "f16x2"
         chunk = self.ROWS_PER_CHUNK
         if query is None:                           # lattice: whole i-slabs per chunk (the brick sampler's unit)
             chunk = max(1, chunk // (Q * Q)) * Q * Q
@@ -170,7 +191,7 @@ class ImplicitWNFDecoder(PackedModule):
                 s = ops.trilinear_sample(vol_b, query=query[m0:m0 + m], out=buf[:m])
             else:
                 s = ops.trilinear_sample(vol_b, Q=Q, m0=m0, M=m, out=buf[:m])
-            if layers is not None and layers[3] is not None and ops.DECODE_MODE == "f16x2":
+            if split:
                 ops.implicit_decode_split(s, layers[3], out=out[m0:m0 + m], xscale=xscale)
                 if xscale is not None:      # the garments the device marked unsafe for fp16 planes: gated fp32 twin (a no-op otherwise)
                     ops.implicit_decode(None, layers[:3], M=m, out=out[m0:m0 + m], xin=s, run_if=xscale[2:3])
@@ -179,78 +200,77 @@ class ImplicitWNFDecoder(PackedModule):
             else:
                 out[m0:m0 + m] = self.mlp(s)
 
-    def forward(self, features_grid, query_points):
+    def forward(self, features_grid, query_points, arith=None):
         """features_grid (B,C,D,H,W), query_points (B,M,3) in [0,1] -> (B,M,out)"""
+        arith = arith or self.arith or AR.DEFAULT
         vol = to_channel_last(features_grid)
         B, M = query_points.shape[:2]
         q = query_points.float().contiguous()
         out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=vol.device)
-        xs = self._volume_scales(vol)
+        xs = self._volume_scales(features_grid, vol, arith)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], query=q[b], xscale=None if xs is None else xs[b])
+            self._decode_rows(vol[b], out[b], query=q[b], xscale=None if xs is None else xs[b], arith=arith)
         return out
 
-    def _volume_scales(self, vol, stats=None, layers=None):
-        """(B, 2) input scales of the split-operand decoder kernel for the channel-last volume the rows are sampled from, or None when
-        that kernel is not the one that runs.  stats: the (sum, sumsq, V) its producer emitted; else one gn_channel_stats pass over the
-        volume, remembered for the same tensor (the reference's chunk loop calls the decoder 8 times per garment on one volume)."""
-        if layers is None:
-            layers = self.packed() if self.fused else None
-        if layers is None or layers[3] is None or ops.DECODE_MODE != "f16x2":
+    def _volume_scales(self, owner, vol, arith):
+        """(B, 4) input scales of the split-operand decoder kernel for the channel-last volume the rows are sampled from, or None when
+        that kernel is not the one that runs.  One gn_channel_stats pass over the volume, remembered ON the caller's tensor object
+        `owner` together with its version counter (the reference's chunk loop calls the decoder 8 times per garment on one volume): the
+        entry dies with the tensor, so a recycled allocation can never be mistaken for it."""
+        layers = self.packed() if self.fused else None
+        if layers is None or layers[3] is None or arith.decode_mode != "f16x2":
             return None
-        if stats is None:
-            key = (vol.data_ptr(), vol._version, tuple(vol.shape))
-            cached = self.__dict__.get("_vol_stats")
-            if cached is None or cached[0] != key:
-                cached = (key, ops.channel_stats(vol))
-                self.__dict__["_vol_stats"] = cached
-            stats = cached[1]
+        cached = getattr(owner, "_gn_chan_stats", None)
+        if cached is None or cached[0] != owner._version:
+            cached = (owner._version, ops.channel_stats(vol))
+            try:
+                owner._gn_chan_stats = cached
+            except AttributeError:
+                pass
+        stats = cached[1]
         return ops.decoder_input_scale(stats[1], stats[2], layers[3].smax)
 
-    def decode_lattice(self, features_grid, Q):
+    def decode_lattice(self, features_grid, Q, arith=None):
         """All (Q,Q,Q) lattice queries of predict.py:145-157 without materialising them -> (B,Q,Q,Q[,out])"""
+        arith = arith or self.arith or AR.DEFAULT
         vol = to_channel_last(features_grid)
         B = vol.shape[0]
         out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
-        xs = self._volume_scales(vol)
+        xs = self._volume_scales(features_grid, vol, arith)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], Q=Q, xscale=None if xs is None else xs[b])
+            self._decode_rows(vol[b], out[b], Q=Q, xscale=None if xs is None else xs[b], arith=arith)
         return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
 
-    def run_on(self, unet3d_result, query_points=None, Q=0):
+    def run_on(self, unet3d_result, query_points=None, Q=0, arith=None):
         """decode against a unet3d_forward result: through the folded first layer when the result still carries the pre-final
         volume (UNetResult) and this decoder can absorb the final convolution, else on the materialised 128-channel volume.
         query_points (B,M,3) -> (B,M,out); query_points None -> the (Q,Q,Q) lattice -> (B,Q,Q,Q[,out])"""
+        arith = arith or self.arith or AR.DEFAULT
         layers = None
-        if isinstance(unet3d_result, UNetResult) and FOLD_FINAL_CONV:
+        if isinstance(unet3d_result, UNetResult) and arith.fold_final_conv:
             layers = self.folded_pack(unet3d_result.final_conv)
         if layers is None:
             vol = unet3d_result["out_feature_volume"]
-            return self.decode_lattice(vol, Q) if query_points is None else self(vol, query_points)
+            return self.decode_lattice(vol, Q, arith) if query_points is None else self(vol, query_points, arith)
         vol = unet3d_result.pre_final
         B = vol.shape[0]
         xs = None
-        if layers[3] is not None and ops.DECODE_MODE == "f16x2":
+        if layers[3] is not None and arith.decode_mode == "f16x2":
             xs = unet3d_result.input_scales(layers[3].smax)
         if query_points is None:
             out = torch.empty((B, Q * Q * Q, self.out_channels), dtype=torch.float32, device=vol.device)
             for b in range(B):
-                self._decode_rows(vol[b], out[b], Q=Q, layers=layers, xscale=None if xs is None else xs[b])
+                self._decode_rows(vol[b], out[b], Q=Q, layers=layers, xscale=None if xs is None else xs[b], arith=arith)
             return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
         q = query_points.float().contiguous()
         out = torch.empty((B, q.shape[1], self.out_channels), dtype=torch.float32, device=vol.device)
         for b in range(B):
-            self._decode_rows(vol[b], out[b], query=q[b], layers=layers, xscale=None if xs is None else xs[b])
+            self._decode_rows(vol[b], out[b], query=q[b], layers=layers, xscale=None if xs is None else xs[b], arith=arith)
         return out
 
 
 # zero-fill of the scattered volume overlapped with PointNet++ (VolumeFeatureAggregator.prefetch_zero)
 PREFETCH_ZERO = os.environ.get("GARMENTNETS_PREFETCH_ZERO", "1") != "0"
-
-# the decoders fold the UNet's final 1x1x1 convolution into their first layer (ImplicitWNFDecoder.folded_pack); False restores the
-# reference's literal order of operations (materialise the 128-channel volume, then sample it)
-FOLD_FINAL_CONV = os.environ.get("GARMENTNETS_FOLD_FINAL_CONV", "1") != "0"
-
 
 class UNetResult(dict):
     """unet3d_forward's result: {'out_feature_volume': (B,128,D,H,W)} as in the reference, except that the 128-channel volume is
@@ -347,6 +367,7 @@ class ConvImplicitWNFPipeline(nn.Module):
             self.mc_surface_decoder = ImplicitWNFDecoder(**mc_surface_decoder_params)
         self.volume_task_space = volume_task_space
         self.batch_size = batch_size
+        self.arith = AR.DEFAULT      # this model's arithmetic (an immutable arith.Arith); every stage method also takes arith= per call
 
     # -- checkpoint ------------------------------------------------------------------------------------------
     @classmethod
@@ -367,9 +388,11 @@ class ConvImplicitWNFPipeline(nn.Module):
         return self.pointnet2_nocs.device
 
     # -- stages ----------------------------------------------------------------------------------------------
-    def pointnet2_forward(self, data):
+    def pointnet2_forward(self, data, prefetch_volume=False):
+        """prefetch_volume: the caller runs unet3d_forward next (and volume_agg.drop_prefetch() on its way out): start the zero-fill
+        of the feature volume beside PointNet++ (VolumeFeatureAggregator.prefetch_zero)"""
         sizes = data._sizes if hasattr(data, "_sizes") else None
-        if sizes is not None and data.pos.is_cuda:   # (no host sizes: the batch size would cost a device synchronisation here)
+        if prefetch_volume and sizes is not None and data.pos.is_cuda:   # (no host sizes: the batch size would cost a device synchronisation here)
             self.volume_agg.prefetch_zero(len(sizes), data.pos.device)
         result = self.pointnet2_nocs(data)
         bins = self.pointnet2_nocs.nocs_bins
@@ -378,38 +401,68 @@ class ConvImplicitWNFPipeline(nn.Module):
                                     sim_points=data.pos, pred_confidence=confidence)
         return result
 
-    def unet3d_forward(self, pointnet2_result):
+    def unet3d_forward(self, pointnet2_result, arith=None):
+        arith = arith or self.arith
         in_feature_volume = self.volume_agg(pointnet2_result["nocs_data"])
         net = self.unet_3d.abstract_3d_unet
         pre, st = net.run(to_channel_last(in_feature_volume), getattr(in_feature_volume, "_gn_stats", None), pre_final=True, return_stats=True,
-                          sparse_flat=getattr(in_feature_volume, "_gn_flat", None))
+                          sparse_flat=getattr(in_feature_volume, "_gn_flat", None), arith=arith)
         return UNetResult(pre, net.final_conv, st)   # ['out_feature_volume'] materialises the reference's tensor on demand
 
-    def volume_decoder_forward(self, unet3d_result, query_points):
-        out = self.volume_decoder.run_on(unet3d_result, query_points)
+    def volume_decoder_forward(self, unet3d_result, query_points, arith=None):
+        out = self.volume_decoder.run_on(unet3d_result, query_points, arith=arith or self.arith)
         return {"out_features": out, "pred_volume_value": out.view(*out.shape[:-1])}
 
-    def surface_decoder_forward(self, unet3d_result, query_points):
-        return {"out_features": self.surface_decoder.run_on(unet3d_result, query_points)}
+    def surface_decoder_forward(self, unet3d_result, query_points, arith=None):
+        return {"out_features": self.surface_decoder.run_on(unet3d_result, query_points, arith=arith or self.arith)}
 
-    def mc_surface_decoder_forward(self, unet3d_result, query_points):
-        return {"out_features": self.mc_surface_decoder.run_on(unet3d_result, query_points)}
+    def mc_surface_decoder_forward(self, unet3d_result, query_points, arith=None):
+        return {"out_features": self.mc_surface_decoder.run_on(unet3d_result, query_points, arith=arith or self.arith)}
 
-    def volume_lattice_forward(self, unet3d_result, volume_size):
+    def volume_lattice_forward(self, unet3d_result, volume_size, arith=None):
         """Whole (Q,Q,Q) WNF volume per garment in one pass (replaces the 64^3 chunk loop of predict.py:145-157)."""
-        return {"pred_volume": self.volume_decoder.run_on(unet3d_result, None, Q=volume_size)}
+        return {"pred_volume": self.volume_decoder.run_on(unet3d_result, None, Q=volume_size, arith=arith or self.arith)}
 
-    def forward(self, data):
-        if self.volume_task_space:
-            raise NotImplementedError("volume_task_space=True is a training-time variant (conv_implicit_wnf.py:279-311)")
-        p2 = self.pointnet2_forward(data)
-        u3 = self.unet3d_forward(p2)
+    @staticmethod
+    def get_aabb_scale_offset(aabb, padding=0.05):
+        """conv_implicit_wnf.py:299-313: per-sample scale / offset that maps the task-space bounding box (B,2,3) into the unit NOCS cube
+        (x, y centred on 0.5, the top of z at 1 - padding)"""
+        nocs_radius = 0.5 - padding
+        radius = torch.max(torch.abs(aabb), dim=1)[0][:, :2]
+        radius_scale = torch.min(nocs_radius / radius, dim=1)[0]
+        z_scale = (nocs_radius * 2) / (aabb[:, 1, 2] - aabb[:, 0, 2])
+        scale = torch.minimum(radius_scale, z_scale)
+        offset = torch.full((len(aabb), 3), 0.5, dtype=aabb.dtype, device=aabb.device)
+        offset[:, 2] = 1 - padding - aabb[:, 1, 2] * scale
+        return scale, offset
+
+    def apply_volume_task_space(self, data, pointnet2_result):
+        """conv_implicit_wnf.py:279-297: the gridding runs on the normalised SIMULATION coordinates of the points instead of their
+        predicted NOCS coordinates (first sample's scale / offset for the whole batch, as the reference)"""
+        scale, offset = self.get_aabb_scale_offset(data.cloth_sim_aabb.to(data.pos.device))
+        nd = pointnet2_result["nocs_data"]
+        new_nd = Batch(sizes=nd._sizes, **{k: getattr(nd, k) for k in nd.keys})
+        new_nd.pos = ((data.pos * scale[0]) + offset[0]).to(torch.float32).contiguous()
+        out = dict(pointnet2_result)
+        out["nocs_data"] = new_nd
+        return out
+
+    def forward(self, data, arith=None):
+        """conv_implicit_wnf.py:315-338"""
+        arith = arith or self.arith
+        try:
+            p2 = self.pointnet2_forward(data, prefetch_volume=True)
+            if self.volume_task_space:
+                p2 = self.apply_volume_task_space(data, p2)
+            u3 = self.unet3d_forward(p2, arith)
+        finally:
+            self.volume_agg.drop_prefetch()
         result = {
             "pointnet2_result": p2,
             "unet3d_result": u3,
-            "volume_decoder_result": self.volume_decoder_forward(u3, data.volume_query_points),
-            "surface_decoder_result": self.surface_decoder_forward(u3, data.surf_query_points),
+            "volume_decoder_result": self.volume_decoder_forward(u3, data.volume_query_points, arith),
+            "surface_decoder_result": self.surface_decoder_forward(u3, data.surf_query_points, arith),
         }
         if self.mc_surface_decoder is not None:
-            result["mc_surface_decoder_result"] = self.mc_surface_decoder_forward(u3, data.mc_surf_query_points)
+            result["mc_surface_decoder_result"] = self.mc_surface_decoder_forward(u3, data.mc_surf_query_points, arith)
         return result

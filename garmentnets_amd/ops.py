@@ -5,7 +5,6 @@ current torch stream.  Tensors must live on a ROCm device -- there is no CPU pat
 """
 import ctypes
 import math
-import os
 
 import numpy as np
 import torch
@@ -292,21 +291,7 @@ def pack_conv_weight(w):
     return w.detach().float().permute(2, 3, 4, 1, 0).reshape(27, cin // 16, 16, cout).permute(0, 1, 3, 2).contiguous()
 
 
-CONV_FP32, SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2 = 0, 2, 3, 4          # 2..4 = GN_SPLIT_* of include/garmentnets_hip.h
-CONV_MODE_NAMES = {"fp32": CONV_FP32, "f16x2": SPLIT_F16X2, "bf16x3": SPLIT_BF16X3, "bf16x2": SPLIT_BF16X2}
-# Arithmetic of the 3x3x3 convolutions (components/unet3d.py reads this on every call):
-#   f16x2  (default) fp32 operands split into two fp16 planes, 3 products on the 16-bit matrix cores, fp32 accumulation
-#          (csrc/unet_split.hip) -- measured error against fp64 is BELOW the fp32-MFMA kernel's (fewer accumulation roundings)
-#   fp32   v_mfma_f32_32x32x2_f32 (csrc/unet.hip): exact fp32 products, 1/16 of the matrix-core rate
-#   bf16x3 / bf16x2: bf16 planes, 6 / 3 products (fp32-class / preview quality)
-def _env_choice(name, default, choices):
-    v = os.environ.get(name, default)
-    if v not in choices:
-        raise ValueError(f"{name}={v!r}: expected one of {sorted(choices)}")
-    return v
-
-
-CONV_MODE = CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)]
+from .arith import CONV_FP32, CONV_MODE_NAMES, SPLIT_BF16X2, SPLIT_BF16X3, SPLIT_F16X2  # noqa: E402,F401  (which arithmetic runs is an arith.Arith carried by the call)
 
 
 class SplitPack:
@@ -359,15 +344,6 @@ def grid_tile_flags(flat_idx, B, grid_shape, reach=1):
     flags = torch.empty((B, tiles), dtype=torch.uint8, device=flat_idx.device)
     _lib.call("gn_grid_tile_flags", _p(_chk(flat_idx, _i32, "flat_idx")), flat_idx.numel(), B, g0, g1, g2, int(reach), _p(flags), _stream())
     return flags
-
-
-# occupancy-aware first two UNet convolutions (exact: bit-identical to the dense launch); "0" = always dense
-SPARSE_FIRST_CONV = os.environ.get("GARMENTNETS_SPARSE_CONV", "1") != "0"
-
-
-# polyphase form of the decoders' first convolutions (nearest-upsampled second source: 8/27 of those channels' MACs, csrc/upconv.hip);
-# "0" = literal form (src1 read at half resolution in the halo stage).  Measured: 163.8 vs 165.8 ms per 16-garment step.
-POLYPHASE_UPCONV = os.environ.get("GARMENTNETS_POLYPHASE", "1") != "0"
 
 
 def polyphase_weights(w, c0):
@@ -508,10 +484,6 @@ def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=
     _lib.call("gn_implicit_decode", _p(vol_b), D, H, W, C0, _p(xin), ldxin, _p(query), int(Q), int(m0), int(M), _p(w1p), _p(b1), _p(s1), _p(t1), N1,
               _p(w2p), _p(b2), _p(s2), _p(t2), N2, _p(w3), _p(b3), _p(s3), _p(t3), OUT, _p(out), rows_view(out)[1], _p(run_if), _stream())
     return out
-
-
-# decoder MLP arithmetic: "f16x2" (default; csrc/decode_split.hip, same operand split as the convs) or "fp32" (csrc/decode.hip)
-DECODE_MODE = _env_choice("GARMENTNETS_DECODE_MODE", "f16x2", ("f16x2", "fp32"))
 
 
 class DecodeSplitPack:

@@ -33,14 +33,14 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_batch(global_batch, n_points, seed, rank, world):
+def shard_batch(global_batch, n_points, seed, rank, world, colour="uniform"):
     """this rank's contiguous shard of the seeded GLOBAL batch of synthetic garments (BASELINE config[3]: 128 garments over 8 GPUs):
     -> (Batch on the host with batch ids restarting at 0, (lo, hi)).  Garment g of the global batch depends on (seed, g) only, so the
     concatenation of the shards over the ranks IS synthetic_cloud(global_batch, n_points, seed) -- tests/test_parallel_cpu.py."""
     from . import synthetic
     from .batch import Batch
     lo, hi = shard_range(global_batch, rank, world)
-    x, pos, batch = synthetic.synthetic_cloud(hi - lo, n_points, seed=seed, first=lo)
+    x, pos, batch = synthetic.synthetic_cloud(hi - lo, n_points, seed=seed, first=lo, colour=colour)
     return Batch(sizes=[n_points] * (hi - lo), x=x, pos=pos, batch=batch), (lo, hi)
 
 
@@ -54,6 +54,17 @@ def gather_metrics(values, device="cpu"):
     v = list(values) + [0.0] * (METRIC_SLOTS - len(values))
     assert len(v) == METRIC_SLOTS
     t = torch.tensor(v, dtype=torch.float64, device=device)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def gather_vector(values, device="cpu"):
+    """all-gather an equal-length list of floats from every rank -> list (per rank) of lists (bench.py: the per-garment result
+    checksums of every shard, so that rank 0 can print them in global garment order)"""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [t.tolist()]
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]

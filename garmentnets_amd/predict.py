@@ -1,4 +1,4 @@
-"""Drop-in for the compute slice of /root/reference/predict.py:138-209.
+"""Drop-in for the compute slice of /root/reference/predict.py:138-209, and (``main``) for its I/O shell :55-279.
 
 ``predict_batch`` runs, for every garment of a batch, exactly the reference's stages
     pointnet2_forward -> unet3d_forward -> (Q,Q,Q) WNF decode -> gaussian_gradient_magnitude -> marching cubes (Lewiner)
@@ -8,12 +8,14 @@ placeholder mesh (predict.py:165-171,188-189).  Results stay on the device; ``to
 numpy dict predict.py writes to zarr (predict.py:191-209).
 
 The CLI reproduces the reference's config keys (config/predict_default.yaml: main.gpu_id, prediction.volume_size,
-gradient_sigma, iso_surface_level, gradient_direction, use_hole_prediction) with argparse; dataset / zarr / wandb I/O
-is out of scope, so inputs are a checkpoint (or seeded synthetic weights) and synthetic clouds.
+gradient_sigma, iso_surface_level, gradient_direction, use_hole_prediction) with argparse.  Inputs: a checkpoint (or seeded synthetic
+weights) and either synthetic clouds or a garmentnets dataset store (``--zarr_in``, io/dataset.py); ``--zarr_out`` writes the
+reference's ``prediction.zarr`` layout INCLUDING the ground-truth half eval.py reads (gt_marching_cubes_mesh, gt_mesh with the
+augmentation rotation, point_cloud/gt_nocs, misc/gt_nocs_grip_point, per-sample attrs: predict.py:120-136,226,236-250,269).
+Hydra / wandb are out of scope.
 """
 import argparse
 import json
-import os
 import time
 
 import numpy as np
@@ -35,63 +37,53 @@ def nan_placeholder(device):
 
 
 _FALLBACKS = {"count": 0}
-# first half's iso-surface graphs beside the second half's lattice decode: measured 170.9 vs 171.5 ms per 16-garment step (noise) -- the
-# side-stream replays already overlap the surface decodes -- so it is off by default
-OVERLAP_ISO = os.environ.get("GARMENTNETS_OVERLAP_ISO", "0") == "1"
+
+
+def _warn_fallback():
+    import warnings
+    _FALLBACKS["count"] += 1
+    if _FALLBACKS["count"] == 1:
+        warnings.warn("garmentnets_amd: NaN in the WNF volume / warp field / hole logits under the split-operand arithmetic (a value left "
+                      "fp16's range, or the input holds NaN): re-running the batch with the fp32 kernels")
 
 
 def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
-                  use_hole_prediction=False, auto_level=False):
+                  use_hole_prediction=False, auto_level=False, arith=None):
     """-> list (one per garment) of dicts of device tensors.
 
-    Arithmetic: the default f16x2 operand split (ops.CONV_MODE / ops.DECODE_MODE) covers fp32's range through power-of-two scales
-    (per output channel, per sample, per hidden unit; csrc/unet_split.hip, csrc/decode_split.hip).  What those cannot cover -- a value
-    beyond fp16's range in the scaled units -- surfaces as NaN in the WNF volume, never as a wrong finite number; such a batch is
-    re-run here with the fp32-MFMA kernels (one warning; the count is in predict._FALLBACKS)."""
-    from . import ops
-    split = ops.CONV_MODE != ops.CONV_FP32 or ops.DECODE_MODE != "fp32"
-    results, bad = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, split)
-    if split and (results is None or bool(bad)):
-        import warnings
-        _FALLBACKS["count"] += 1
-        if _FALLBACKS["count"] == 1:
-            warnings.warn("garmentnets_amd: NaN in the WNF volume under the split-operand arithmetic (a value left fp16's range, or the input "
-                          "holds NaN): re-running the batch with the fp32 kernels")
-        saved = (ops.CONV_MODE, ops.DECODE_MODE)
-        try:
-            ops.CONV_MODE, ops.DECODE_MODE = ops.CONV_FP32, "fp32"
-            results, _ = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, False)
-        finally:
-            ops.CONV_MODE, ops.DECODE_MODE = saved
+    Arithmetic: ``arith`` (default: the model's, ``model.arith``; an immutable arith.Arith passed down every call -- nothing global is
+    switched).  The default f16x2 operand split covers fp32's range through power-of-two scales (per output channel, per sample, per
+    hidden unit; csrc/unet_split.hip, csrc/decode_split.hip).  What those cannot cover -- a value beyond fp16's range in the scaled
+    units -- surfaces as NaN in the WNF volume, the warp field or the hole logits (each decoder has its own weights and scales), never
+    as a wrong finite number; such a batch is re-run here with ``arith.strict_fp32()`` (one warning; the count is in
+    predict._FALLBACKS)."""
+    arith = arith or model.arith
+    results, bad = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level,
+                                       arith.split, arith)
+    if arith.split and (results is None or bool(bad)):
+        _warn_fallback()
+        results, _ = _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level,
+                                         False, arith.strict_fp32())
     return results
 
 
-def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, iso_bank=0):
+def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, arith):
     """everything that needs no host synchronisation, queued on the current stream: PointNet++ -> gridding + UNet -> WNF lattice ->
-    (fixed level) the per-garment GGM / MC33 slot graphs on the iso side streams -> the batch's grip-point post-processing.
-    -> state dict for _tail_phase"""
+    (fixed level) GGM / MC33 of the whole batch -> the batch's grip-point post-processing.  -> state dict for _tail_phase"""
     with torch.no_grad():
-        pointnet2_result = model.pointnet2_forward(batch)
-        unet3d_result = model.unet3d_forward(pointnet2_result)
+        try:
+            pointnet2_result = model.pointnet2_forward(batch, prefetch_volume=True)
+            unet3d_result = model.unet3d_forward(pointnet2_result, arith)
+        finally:
+            model.volume_agg.drop_prefetch()
         nocs_data = pointnet2_result["nocs_data"]
         B = nocs_data.num_graphs
-        # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first).
-        # OVERLAP_ISO: the lattice is decoded in two halves, the first half's GGM / marching-cubes graphs (small, latency-bound grids on
-        # side streams) run beside the second half's decoder MLP (matrix-core bound)
+        wnf_all = model.volume_lattice_forward(unet3d_result, volume_size, arith)["pred_volume"]     # (B,Q,Q,Q)
+        # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first)
         job = None
-        if auto_level or B < 4 or not OVERLAP_ISO:
-            wnf_all = model.volume_lattice_forward(unet3d_result, volume_size)["pred_volume"]     # (B,Q,Q,Q)
-            if not auto_level:
-                job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, bank=iso_bank)
-                job.enqueue(wnf_all)
-        else:
-            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, bank=iso_bank)
-            parts = []
-            for b0, b1 in ((0, B // 2), (B // 2, B)):
-                part = model.volume_lattice_forward(unet3d_result.select(b0, b1), volume_size)["pred_volume"]
-                job.enqueue(part)
-                parts.append(part)
-            wnf_all = torch.cat(parts)
+        if not auto_level:
+            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction)
+            job.enqueue(wnf_all)
         bad = torch.isnan(wnf_all).any()             # read after the batch's own host synchronisation
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
         bins = model.pointnet2_nocs.nocs_bins
@@ -107,10 +99,10 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
                     grip_global=grip_global, conf_global=conf_global, grip_nocs=grip_nocs)
 
 
-def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
+def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan, arith):
     """the host-synchronising rest, on the current stream: vertex / face counts of the batch (one device-to-host copy), per garment
-    the mesh slices, the GGM look-up and the surface decoders.  -> (results, device bool: the WNF holds a NaN); stop_on_nan: ->
-    (None, True) before the per-garment tail when it does"""
+    the mesh slices, the GGM look-up and the surface decoders.  -> (results, device bool: the WNF, the warp field or the hole logits
+    hold a NaN); stop_on_nan: -> (None, True) before the per-garment tail when the WNF does"""
     with torch.no_grad():
         pointnet2_result, unet3d_result, wnf_all, bad = st["pointnet2_result"], st["unet3d_result"], st["wnf_all"], st["bad"]
         nocs_data = pointnet2_result["nocs_data"]
@@ -126,9 +118,11 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
         q_all = st["job"].padded_queries() if st["job"] is not None else None
         warp_all = hole_all = None
         if q_all is not None:
-            warp_all = model.surface_decoder_forward(unet3d_result, q_all)["out_features"]
+            warp_all = model.surface_decoder_forward(unet3d_result, q_all, arith)["out_features"]
+            bad = bad | torch.isnan(warp_all).any()  # the surface decoders run the split kernel with their OWN weights and scales
             if use_hole_prediction:
-                hole_all = model.mc_surface_decoder_forward(unet3d_result, q_all)["out_features"]
+                hole_all = model.mc_surface_decoder_forward(unet3d_result, q_all, arith)["out_features"]
+                bad = bad | torch.isnan(hole_all).any()
         for b in range(B):
             wnf = wnf_all[b]
             res = dict(wnf_volume=wnf)
@@ -150,8 +144,12 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
                 else:
                     u3_b = unet3d_result.select(b, b + 1)          # the 128-channel volume is never materialised on this path
                     q = mesh["verts_f32"].view(1, -1, 3)
-                    mesh["warp_field"] = model.surface_decoder_forward(u3_b, q)["out_features"].view(-1, 3)
-                    logits = model.mc_surface_decoder_forward(u3_b, q)["out_features"].reshape(-1) if use_hole_prediction else None
+                    mesh["warp_field"] = model.surface_decoder_forward(u3_b, q, arith)["out_features"].view(-1, 3)
+                    bad = bad | torch.isnan(mesh["warp_field"]).any()
+                    logits = None
+                    if use_hole_prediction:
+                        logits = model.mc_surface_decoder_forward(u3_b, q, arith)["out_features"].reshape(-1)
+                        bad = bad | torch.isnan(logits).any()
                 if use_hole_prediction:
                     mesh["is_on_surface_logits"] = logits
                     mesh["is_on_surface"] = logits > 0
@@ -169,10 +167,10 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
         return results, bad
 
 
-def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan):
-    """-> (results, device bool: the WNF holds a NaN); stop_on_nan: -> (None, True) before the per-garment tail when it does"""
-    st = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level)
-    return _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan)
+def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan, arith):
+    """-> (results, device bool: NaN seen); stop_on_nan: -> (None, True) before the per-garment tail when the WNF holds one"""
+    st = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, arith)
+    return _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan, arith)
 
 
 _TAIL_STREAMS = {}
@@ -180,24 +178,21 @@ _TAIL_STREAMS = {}
 
 class PredictJob:
     """predict_batch in two halves, for a stream of batches: the constructor queues everything that needs no host synchronisation
-    (PointNet++, UNet, WNF lattice on the current stream; the per-garment GGM / MC33 slot graphs on the iso side streams) and returns;
-    ``finish()`` does the rest -- the one device-to-host copy of the vertex / face counts, the mesh slices, the surface decoders --
-    on a tail stream of its own, so that it waits for THIS batch's iso-surfaces only, not for whatever the caller has queued on the
-    main stream since.  Begin batch k+1, then finish batch k: the latency-bound tail of k (small grids, host round trip) and the
-    16-workgroup farthest-point sampling of k+1 fill each other's idle CUs, and the host's launch gaps disappear behind queued work.
-    Two banks of iso slot buffers (``bank`` = 1 + (k & 1); predict_batch uses bank 0) keep batch k's marching-cubes outputs intact
-    while k+1's are produced: a bank belongs to its job until finish().
+    (PointNet++, UNet, WNF lattice, the batch's GGM / MC33 launches on the current stream) and returns; ``finish()`` does the rest --
+    the one device-to-host copy of the vertex / face counts, the mesh slices, the surface decoders -- on a tail stream of its own, so
+    that it waits for THIS batch's iso-surfaces only, not for whatever the caller has queued on the main stream since.  Begin batch
+    k+1, then finish batch k: the latency-bound tail of k (small grids, host round trip) and the 16-workgroup farthest-point sampling
+    of k+1 fill each other's idle CUs, and the host's launch gaps disappear behind queued work.  Every job owns its buffers.
     Same results as predict_batch, bit for bit (tests/test_gpu_api.py)."""
 
     def __init__(self, model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
-                 use_hole_prediction=False, bank=1):
-        from . import ops
+                 use_hole_prediction=False, arith=None):
         self.model, self.batch = model, batch
         self.args = (volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction)
-        self.split = ops.CONV_MODE != ops.CONV_FP32 or ops.DECODE_MODE != "fp32"
+        self.arith = arith or model.arith
         self.device = batch.pos.device
         self.main = torch.cuda.current_stream(self.device)
-        self.state = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, False, iso_bank=bank)
+        self.state = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, False, self.arith)
         self.ready = torch.cuda.Event()
         self.ready.record(self.main)
 
@@ -205,37 +200,39 @@ class PredictJob:
         """-> what predict_batch returns; host=True: -> [to_host(r) for r in results], copied on the tail stream (the copies wait for this
         batch only, not for the next batch's dense path on the caller's stream)"""
         volume_size, level, sigma, direction, hole = self.args
+        split = self.arith.split
         tail = _TAIL_STREAMS.get(str(self.device))
         if tail is None:
             tail = _TAIL_STREAMS[str(self.device)] = torch.cuda.Stream(device=self.device)
         tail.wait_event(self.ready)
         with torch.cuda.stream(tail):
-            results, bad = _tail_phase(self.model, self.batch, self.state, level, sigma, direction, hole, False, self.split)
-            if host and results is not None and not (self.split and bool(bad)):
+            results, bad = _tail_phase(self.model, self.batch, self.state, level, sigma, direction, hole, False, split, self.arith)
+            nan_seen = split and (results is None or bool(bad))
+            if host and not nan_seen:
                 results = [to_host(r) for r in results]
                 self.state = None
                 return results
         cur = torch.cuda.current_stream(self.device)
         cur.wait_stream(tail)                       # the caller's stream sees finished results; main-stream memory the tail read is safe to recycle
-        if self.split and (results is None or bool(bad)):
-            self.state = None
-            results = predict_batch(self.model, self.batch, volume_size, level, sigma, direction, hole, False)   # (takes the fp32 re-run path)
+        self.state = None
+        if nan_seen:                                # the fp32 re-run of THIS batch: its own arith value travels down its own calls
+            _warn_fallback()
+            results, _ = _predict_batch_once(self.model, self.batch, volume_size, level, sigma, direction, hole, False, False, self.arith.strict_fp32())
             return [to_host(r) for r in results] if host else results
         for r in results:                           # allocated on the tail stream, consumed on the caller's
             for v in r.values():
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(cur)
-        self.state = None
         return results
 
 
 def predict_stream(model, batches, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
-                   use_hole_prediction=False):
+                   use_hole_prediction=False, arith=None):
     """generator over an iterable of batches -> the predict_batch result of each, in order, with one batch in flight behind the one
     being finished (PredictJob)"""
     prev = None
-    for k, batch in enumerate(batches):
-        job = PredictJob(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, bank=1 + (k & 1))
+    for batch in batches:
+        job = PredictJob(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, arith)
         if prev is not None:
             yield prev.finish()
         prev = job
@@ -257,17 +254,54 @@ def to_host(res):
     return out
 
 
-def to_host_groups(res):
-    """(marching_cubes_mesh, point_cloud, misc) numpy dicts = the three zarr groups predict.py:211-279 writes per sample."""
+def to_host_groups(res, data=None):
+    """(marching_cubes_mesh, point_cloud, misc) numpy dicts = the three zarr groups predict.py:211-279 writes per sample.
+    data: the (one-garment) input Batch of a dataset sample -- adds its ground truth as the reference does: point_cloud/gt_nocs =
+    batch.y (predict.py:226), misc/gt_nocs_grip_point = batch.nocs_grip_point[0] (predict.py:269)"""
     pc = {"pred_nocs": to_numpy(res["pred_nocs"]), "pred_nocs_confidence": to_numpy(res["pred_nocs_confidence"]),
           "pred_nocs_logits": to_numpy(res["pred_nocs_logits"]), "input_points": to_numpy(res["input_points"]),
           "input_rgb": to_numpy((res["input_rgb"] * 255).to(torch.uint8))}
-    misc = {k: to_numpy(res[k]) for k in ("pred_nocs_grip_point", "pred_global_nocs_grip_point", "pred_global_confidence", "global_feature")}
+    misc = {}
+    if data is not None and hasattr(data, "y"):
+        pc["gt_nocs"] = to_numpy(data.y)
+    if data is not None and hasattr(data, "nocs_grip_point"):
+        misc["gt_nocs_grip_point"] = to_numpy(data.nocs_grip_point)[0]
+    misc.update({k: to_numpy(res[k]) for k in ("pred_nocs_grip_point", "pred_global_nocs_grip_point", "pred_global_confidence", "global_feature")})
     return to_host(res), pc, misc
 
 
+SAMPLE_ATTR_KEYS = ("scale", "gender", "sample_id", "garment_name", "grip_vertex_idx")      # predict.py:124-130
+
+
+def write_prediction_sample(output_samples_group, group_key, res, data=None, input_group=None, batch_idx=0, compressor=("zlib", 1)):
+    """one sample of prediction.zarr, predict.py:120-136,211-279: the predicted marching_cubes_mesh / point_cloud / misc groups and -- for
+    a dataset sample (`data` = its one-garment Batch, `input_group` = its group in the INPUT store) -- everything eval.py reads next to
+    them (eval.py:58-66,106-110,147-152,193-208): the per-sample attrs, ``gt_marching_cubes_mesh`` (a copy of the input sample's
+    ``marching_cube_mesh`` group, chunk files and codec as they are: what zarr.copy does) and ``gt_mesh`` (the input ``mesh`` arrays,
+    ``cloth_verts`` rotated by the augmentation matrix the cloud was rotated with)."""
+    from .io import zarr_store
+    attrs = {"batch_idx": int(batch_idx)}
+    if input_group is not None:
+        src = input_group.attrs
+        for k in SAMPLE_ATTR_KEYS:
+            if k in src:
+                attrs[k] = int(src[k]) if k in ("gender", "grip_vertex_idx") else src[k]
+    mesh, pc, misc = to_host_groups(res, data)
+    g = zarr_store.write_sample(output_samples_group, group_key, mesh, pc, misc, attrs=attrs, compressor=compressor)
+    if input_group is not None:
+        if "marching_cube_mesh" in input_group:
+            zarr_store.copy_group(input_group["marching_cube_mesh"], g, "gt_marching_cubes_mesh")
+        rot = np.eye(3, dtype=np.float32)
+        if data is not None and hasattr(data, "input_aug_rot_mat"):
+            rot = np.squeeze(to_numpy(data.input_aug_rot_mat))
+        out_mesh = g.require_group("gt_mesh")
+        for key, value in input_group["mesh"].arrays():
+            out_mesh.array(key, value @ rot.T if key == "cloth_verts" else value, compressor=compressor)
+    return g
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="GarmentNets predict (MI355X-native), synthetic-input mode")
+    ap = argparse.ArgumentParser(description="GarmentNets predict (MI355X-native): predict.py's loop over a dataset store or synthetic clouds")
     ap.add_argument("--checkpoint_path", default=None, help="Lightning-style .ckpt; default: seeded synthetic weights")
     ap.add_argument("--gpu_id", type=int, default=0)
     ap.add_argument("--volume_size", type=int, default=128)
@@ -275,15 +309,21 @@ def main(argv=None):
     ap.add_argument("--iso_surface_level", type=float, default=0.5)
     ap.add_argument("--gradient_direction", default="ascent")
     ap.add_argument("--use_hole_prediction", action="store_true")
+    ap.add_argument("--auto_level", action="store_true", help="synthetic weights: iso level = mid(min, max) of each WNF volume instead of the fixed level")
     ap.add_argument("--num_samples", type=int, default=4)
     ap.add_argument("--num_pc_sample", type=int, default=6000)
     ap.add_argument("--grid", type=int, default=32)
     ap.add_argument("--reduce_method", default="max")
+    ap.add_argument("--subset", default="test", help="prediction.subset of the reference config (recorded in the output store's root attrs)")
     ap.add_argument("--out", default=None, help="optional .npz with the last mesh")
     ap.add_argument("--zarr_out", default=None, help="optional prediction.zarr directory (reference group layout, Zarr v2)")
     ap.add_argument("--zarr_in", default=None, help="garmentnets dataset (Zarr v2, zlib / uncompressed chunks): read the clouds through "
-                                                    "io.dataset.GarmentInputDataset (num_views / static seed / no augmentation as in predict_default.yaml) instead of synthetic ones")
+                                                    "io.dataset.GarmentInputDataset instead of synthetic ones; with --zarr_out the ground-truth groups eval.py "
+                                                    "reads are written too")
     ap.add_argument("--num_views", type=int, default=4)
+    ap.add_argument("--no_augmentation", action="store_true", help="datamodule.enable_augumentation=False (predict_default.yaml: True)")
+    ap.add_argument("--random_rot_range", type=float, nargs=2, default=(-180.0, 180.0))
+    ap.add_argument("--static_epoch_seed", action="store_true", help="datamodule.static_epoch_seed=True (predict_default.yaml: False)")
     a = ap.parse_args(argv)
     device = torch.device("cuda:{}".format(a.gpu_id))
     torch.cuda.set_device(device)       # main.gpu_id of the reference config: every allocation, stream and kernel of this process goes there
@@ -298,7 +338,15 @@ def main(argv=None):
     dataset = None
     if a.zarr_in:
         from .io.dataset import GarmentInputDataset
-        dataset = GarmentInputDataset(a.zarr_in, num_pc_sample=a.num_pc_sample, num_views=a.num_views, static_epoch_seed=True, enable_augumentation=False)
+        dataset = GarmentInputDataset(a.zarr_in, num_pc_sample=a.num_pc_sample, num_views=a.num_views, static_epoch_seed=a.static_epoch_seed,
+                                      enable_augumentation=not a.no_augmentation, random_rot_range=tuple(a.random_rot_range),
+                                      volume_task_space=model.volume_task_space)
+    out_samples = None
+    if a.zarr_out:
+        from .io import zarr_store
+        root = zarr_store.open_group(a.zarr_out)
+        root.put_attrs({"subset": a.subset if dataset is not None else "synthetic"})
+        out_samples = root.require_group("samples")
     for i in range(min(a.num_samples, len(dataset)) if dataset is not None else a.num_samples):   # batch_size == 1 as asserted by predict.py:62
         if dataset is not None:
             data = GarmentInputDataset.collate([dataset[i]])
@@ -306,15 +354,14 @@ def main(argv=None):
             x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
             data = Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch)
         t0 = time.time()
-        res = predict_batch(model, data.to(device), a.volume_size,
-                            a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction)[0]
+        res = predict_batch(model, data.to(device), a.volume_size, a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction,
+                            auto_level=a.auto_level)[0]
         last = to_host(res)
-        if a.zarr_out:
-            from .io import zarr_store
-            root = zarr_store.open_group(a.zarr_out)
-            root.put_attrs({"subset": "synthetic"})
-            mesh, pc, misc = to_host_groups(res)
-            zarr_store.write_sample(root.require_group("samples"), f"synthetic_{i:05d}", mesh, pc, misc, attrs={"batch_idx": i})
+        if out_samples is not None:
+            if dataset is not None:
+                write_prediction_sample(out_samples, dataset.keys[i], res, data, dataset.samples_group[dataset.keys[i]], batch_idx=i)
+            else:
+                write_prediction_sample(out_samples, f"synthetic_{i:05d}", res, batch_idx=i)
         torch.cuda.synchronize()
         print(json.dumps({"sample": i, "verts": int(last["verts"].shape[0]), "faces": int(last["faces"].shape[0]),
                           "seconds": round(time.time() - t0, 4)}))

@@ -118,12 +118,67 @@ def synthetic_tensor(key, shape, seed=0):
     raise KeyError(key)
 
 
-def synthetic_state_dict(hp, seed=0):
-    return {k: synthetic_tensor(k, shp, seed) for k, shp in state_dict_spec(hp)}
+def synthetic_state_dict(hp, seed=0, planted_nocs=False):
+    """planted_nocs: see plant_nocs_path (bench.py's default weights)"""
+    sd = {k: synthetic_tensor(k, shp, seed) for k, shp in state_dict_spec(hp)}
+    return plant_nocs_path(sd, hp) if planted_nocs else sd
 
 
-def synthetic_cloud(num_garments, n_points=6000, seed=0, first=0):
+NOCS_PLANT_GAP = 8.0      # logit margin between the planted arg-max bin and its neighbours
+
+
+def plant_nocs_path(sd, hp, prefix="pointnet2_nocs"):
+    """Seeded random weights predict the SAME few NOCS bins for every point of a cloud (the 6000 points collapse into ~5 of the 2 M cells of a
+    128^3 grid): a degenerate input for everything behind the gridding (GroupNorm over a > 99.99 % empty volume amplifies rounding ~100x)
+    and nothing like what a trained PointNet++ produces.  This plants ONE trained-like behaviour into the random checkpoint, inside the
+    reference's own schema (the result loads into the reference's modules unchanged): the NOCS head reads the per-point input feature
+    ``x`` (the cloud's colour channels, networks/pointnet2_nocs.py:145-157 -- the only absolute per-point quantity the architecture
+    carries to the head) through an identity path
+
+        fp1_module.nn.{0,1,2} channel j <- x_j   (Linear row = unit vector, bias 0, BatchNorm = identity)
+        lin1, lin2            channel j <- channel j
+        lin3                  logit (bin k, axis a) += s (2 c_a k/63 - (k/63)^2)    [= -s (c_a - k/63)^2 + const: arg-max = nearest bin]
+
+    on top of the random weights of all other channels (which keep reading the planted ones).  With ``synthetic_cloud(colour="position")``
+    -- x := the garment's normalised, 64-bin quantised point positions -- the predicted NOCS coordinates spread over the garment's own
+    shape (thousands of occupied cells); the margin to the neighbouring bins is NOCS_PLANT_GAP logits, the random channels add O(1) on
+    top, so the soft-max confidence stays a non-trivial per-point quantity (0.99-0.9999)."""
+    bins = hp["pointnet2_params"]["nocs_bins"]
+    assert bins is not None and hp["pointnet2_params"].get("batch_norm", True)
+    sd = dict(sd)
+    ident = torch.eye(3)
+    for i, col0 in ((0, 128), (1, 0), (2, 0)):
+        p = f"{prefix}.fp1_module.nn.{i}"
+        w = sd[p + ".0.weight"].clone()
+        w[:3] = 0.0
+        w[:3, col0:col0 + 3] = ident
+        sd[p + ".0.weight"] = w
+        for key, val in ((".0.bias", 0.0), (".2.weight", 1.0), (".2.bias", 0.0), (".2.running_mean", 0.0), (".2.running_var", 1.0)):
+            t = sd[p + key].clone()
+            t[:3] = val
+            sd[p + key] = t
+    for name in ("lin1", "lin2"):
+        w, b = sd[f"{prefix}.{name}.weight"].clone(), sd[f"{prefix}.{name}.bias"].clone()
+        w[:3] = 0.0
+        w[:3, :3] = ident
+        b[:3] = 0.0
+        sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"] = w, b
+    s = NOCS_PLANT_GAP * float(bins - 1) ** 2
+    w, b = sd[f"{prefix}.lin3.weight"].clone(), sd[f"{prefix}.lin3.bias"].clone()
+    w[:, :3] = 0.0
+    k = torch.arange(bins, dtype=torch.float64) / (bins - 1)
+    for a in range(3):                                  # logits are laid out (bin, axis): networks/conv_implicit_wnf.py:220-224
+        w[a::3, a] = (2.0 * s * k).float()
+        b[a::3] = b[a::3] - (s * k * k).float()
+    sd[f"{prefix}.lin3.weight"], sd[f"{prefix}.lin3.bias"] = w, b
+    return sd
+
+
+def synthetic_cloud(num_garments, n_points=6000, seed=0, first=0, colour="uniform"):
     """-> x (N,3) rgb in [0,1], pos (N,3) metres in the gripper frame, batch (N,) int64 sorted.
+    colour: "uniform" = rgb ~ U(0,1); "position" = rgb := the garment's own normalised point positions, quantised to the
+    64 NOCS bins in [0.1, 0.9] (a garment whose texture encodes where on the garment a point lies -- the input plant_nocs_path's NOCS
+    head decodes, bench.py's default).
     Garment g of the seed's stream depends on (seed, g) only: ``first`` selects garments first..first+num_garments-1, i.e. exactly the
     slice [first, first+num) of the global batch synthetic_cloud(total, n, seed) (a rank's shard of it, batch ids restarting at 0)."""
     xs, ps, bs = [], [], []
@@ -137,6 +192,11 @@ def synthetic_cloud(num_garments, n_points=6000, seed=0, first=0):
             if len(np.unique(pos, axis=0)) == n_points:
                 break
         rgb = rng.uniform(0, 1, (n_points, 3)).astype(np.float32)
+        if colour == "position":
+            mn, mx = pos.min(axis=0, keepdims=True), pos.max(axis=0, keepdims=True)
+            rgb = (np.round((0.1 + 0.8 * (pos - mn) / (mx - mn)) * 63.0) / 63.0).astype(np.float32)
+        elif colour != "uniform":
+            raise ValueError(f"colour={colour!r}")
         xs.append(rgb)
         ps.append(pos)
         bs.append(np.full(n_points, b, np.int64))

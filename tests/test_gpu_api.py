@@ -2,6 +2,11 @@
 the hole-prediction head (predict.py:202-209), ConvImplicitWNFPipeline.forward(data) with explicit query sets
 (networks/conv_implicit_wnf.py:314-338), delete_invalid_verts on device tensors (common/marching_cubes_util.py:38-52), the sharded
 (N > 1) data path run rank by rank on the one GPU, and a non-default device when the box has one."""
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -9,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import pipeline as P  # noqa: E402
-from garmentnets_amd import ops, parallel, synthetic as S  # noqa: E402
+from garmentnets_amd import arith as AR, ops, parallel, synthetic as S  # noqa: E402
 from garmentnets_amd.batch import Batch  # noqa: E402
 from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline  # noqa: E402
 from garmentnets_amd.predict import predict_batch, to_host  # noqa: E402
@@ -156,7 +161,7 @@ def test_non_default_device():
 
 def test_predict_stream_equals_predict_batch():
     """predict.PredictJob / predict_stream (batch k+1's dense path queued before batch k's host-synchronising tail, tails on their own
-    stream, two banks of iso slot buffers): every garment of every batch bit-equal to predict_batch run batch by batch -- including a
+    stream, every job with its own iso-surface buffers): every garment of every batch bit-equal to predict_batch run batch by batch -- including a
     batch whose meshes are empty at the fixed level (placeholder path) and the hole-prediction head"""
     from garmentnets_amd.predict import PredictJob, predict_stream
     hp = S.default_hparams(grid=32, reduce_method="mean", mc_surface=True)
@@ -185,12 +190,267 @@ def test_predict_stream_equals_predict_batch():
                 assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), k
             n_real += int(not torch.isnan(r["verts"]).any())
     assert n_real >= 3
-    # twice over the same batches (slot banks and the tail stream reused), interleaved with a plain predict_batch on the main stream
-    j0 = PredictJob(model, batches[1], 32, level, bank=1)      # (predict_batch itself uses bank 0)
-    j1 = PredictJob(model, batches[2], 32, level, bank=2)
+    # twice over the same batches (the tail stream reused), interleaved with a plain predict_batch on the main stream
+    j0 = PredictJob(model, batches[1], 32, level)              # (every job owns its buffers)
+    j1 = PredictJob(model, batches[2], 32, level)
     mid = predict_batch(model, batches[3], volume_size=32, iso_surface_level=level)
     r0, r1 = j0.finish(), j1.finish()
     for rb, gb in ((ref[1], r0), (ref[2], r1), (ref[3], mid)):
         for r, g in zip(rb, gb):
             assert torch.equal(r["faces"], g["faces"]) and torch.equal(torch.nan_to_num(r["verts"], nan=-7.0), torch.nan_to_num(g["verts"], nan=-7.0))
             assert torch.equal(torch.nan_to_num(r["warp_field"], nan=-7.0), torch.nan_to_num(g["warp_field"], nan=-7.0))
+
+
+def test_forward_volume_task_space_against_oracle():
+    """ConvImplicitWNFPipeline(volume_task_space=True).forward(data) (networks/conv_implicit_wnf.py:279-311,321-323): the gridding runs on
+    the normalised simulation coordinates (scale / offset from data.cloth_sim_aabb, first sample's for the whole batch) instead of the
+    predicted NOCS coordinates -- scale / offset against a restatement of :299-313, the gridded cells exactly, the decoders within 1e-4
+    of the oracle chain fed the same positions"""
+    hp = S.default_hparams(grid=32, reduce_method="mean")
+    hp["volume_task_space"] = True
+    sd = S.synthetic_state_dict(hp, 4)
+    model = _model(hp, 4)
+    assert model.volume_task_space
+    x, pos, batch = S.synthetic_cloud(2, 2000, seed=9)
+    aabb = torch.tensor([[[-0.32, -0.30, -0.85], [0.31, 0.33, 0.02]]], dtype=torch.float32).repeat(2, 1, 1)
+    aabb[1] *= 1.3                                                 # (only the first sample's scale / offset is used, as in the reference)
+    g = torch.Generator().manual_seed(2)
+    vq, sq = torch.rand(2, 500, 3, generator=g), torch.rand(2, 200, 3, generator=g)
+    data = Batch(sizes=[2000, 2000], x=x, pos=pos, batch=batch, volume_query_points=vq, surf_query_points=sq, cloth_sim_aabb=aabb).to(DEV)
+    with torch.no_grad():
+        out = model(data)
+    # conv_implicit_wnf.py:299-313 restated on the host
+    nr = 0.45
+    radius = aabb.abs().max(dim=1)[0][:, :2]
+    scale = torch.minimum((nr / radius).min(dim=1)[0], (2 * nr) / (aabb[:, 1, 2] - aabb[:, 0, 2]))
+    offset = torch.full((2, 3), 0.5)
+    offset[:, 2] = 1 - 0.05 - aabb[:, 1, 2] * scale
+    sc, of = model.get_aabb_scale_offset(aabb)
+    assert torch.equal(sc, scale) and torch.equal(of, offset)
+    new_pos = pos * scale[0] + offset[0]
+    nd = out["pointnet2_result"]["nocs_data"]
+    assert torch.equal(nd.pos.cpu(), new_pos) and float(new_pos.min()) >= 0.0 and float(new_pos.max()) <= 1.0
+    ref_p2 = P.pointnet2_forward(sd, hp, x, pos, batch)
+    ref_nd = dict(ref_p2["nocs_data"])
+    ref_nd["pos"] = new_pos
+    ref_vin = P.volume_agg(sd, hp["volume_agg_params"], ref_nd, 2)
+    with torch.no_grad():
+        vin = model.volume_agg(nd)
+    assert torch.equal(vin.cpu() != 0, ref_vin != 0)
+    ref_vol = P.unet3d(sd, hp["unet3d_params"], ref_vin)
+    np.testing.assert_allclose(out["volume_decoder_result"]["pred_volume_value"].cpu().numpy(),
+                               P.implicit_decoder(sd, "volume_decoder", ref_vol, vq).squeeze(-1).numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(out["surface_decoder_result"]["out_features"].cpu().numpy(), P.implicit_decoder(sd, "surface_decoder", ref_vol, sq).numpy(),
+                               rtol=0, atol=TOL)
+
+
+def test_surface_decoder_nan_triggers_the_fp32_rerun(monkeypatch):
+    """the surface / hole decoders run the split-operand kernel with their OWN weights and scales: a NaN there (finite WNF) must also
+    send the batch to the fp32 kernels -- predict_batch and PredictJob.finish alike"""
+    from garmentnets_amd import predict as PR
+    hp = S.default_hparams(grid=16, reduce_method="max", mc_surface=True)
+    model = _model(hp, 3)
+    x, pos, batch = S.synthetic_cloud(2, 1500, seed=5)
+    data = Batch(sizes=[1500, 1500], x=x, pos=pos, batch=batch).to(DEV)
+    probe = predict_batch(model, data, volume_size=24, auto_level=True)
+    w = probe[0]["wnf_volume"]
+    level = 0.5 * (float(w.min()) + float(w.max()))
+    want = predict_batch(model, data, volume_size=24, iso_surface_level=level, use_hole_prediction=True, arith=model.arith.strict_fp32())
+    assert not any(bool(torch.isnan(r["verts"]).any()) for r in want)
+    orig = ops.implicit_decode_split
+    for which in (3, 1):                                   # poison the warp-field decoder (3 outputs), then the hole decoder (1 output, surface queries)
+        state = {"armed": True}
+
+        def poisoned(xin, pack, out=None, xscale=None, _which=which):
+            r = orig(xin, pack, out=out, xscale=xscale)
+            if state["armed"] and pack.out_channels == _which and r.shape[0] != 24 * 24 * 24 and r.shape[0] > 0:
+                r[0] = float("nan")
+                state["armed"] = False
+            return r
+        monkeypatch.setattr(ops, "implicit_decode_split", poisoned)
+        for runner in ("batch", "job"):
+            state["armed"] = True
+            PR._FALLBACKS["count"] = 0
+            with pytest.warns(UserWarning):
+                if runner == "batch":
+                    got = predict_batch(model, data, volume_size=24, iso_surface_level=level, use_hole_prediction=True)
+                else:
+                    got = PR.PredictJob(model, data, 24, level, use_hole_prediction=True).finish()
+            assert PR._FALLBACKS["count"] == 1 and not state["armed"], (which, runner)
+            for a, b in zip(got, want):
+                assert torch.equal(a["warp_field"], b["warp_field"]) and torch.equal(a["is_on_surface_logits"], b["is_on_surface_logits"])
+                assert torch.equal(a["wnf_volume"], b["wnf_volume"]) and torch.equal(a["faces"], b["faces"])
+        monkeypatch.setattr(ops, "implicit_decode_split", orig)
+
+
+def test_decoder_input_scale_is_not_keyed_on_a_recycled_address():
+    """ImplicitWNFDecoder called directly on materialised volumes (the reference's literal path): batch k+1's volume usually lands at the
+    address batch k's was freed from, with the same shape and version -- its fp16 input scale must come from ITS statistics.  The second
+    volume is 2^20 times larger: with the first one's scale the split kernel overflows fp16 (NaN) or loses the second plane."""
+    from garmentnets_amd.networks.conv_implicit_wnf import ImplicitWNFDecoder
+    dec = ImplicitWNFDecoder((128, 256, 256, 1), batch_norm=True)
+    dec.load_state_dict({k: S.synthetic_tensor("volume_decoder." + k, tuple(v.shape), seed=3) for k, v in dec.state_dict().items()})
+    dec = dec.to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    q = torch.rand(1, 4096, 3, generator=g).to(DEV)
+    base = torch.randn(1, 128, 8, 8, 8, generator=g)
+    ptrs, errs = [], []
+    for k, gain in enumerate((1.0, 2.0 ** 20, 2.0 ** -20)):
+        vol = (base * gain).to(DEV)
+        ptrs.append(vol.data_ptr())
+        with torch.no_grad():
+            out = dec(vol, q)
+            ref = dec(vol, q, arith=AR.DEFAULT.strict_fp32())
+        assert bool(torch.isfinite(out).all())
+        errs.append(float((out - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+        del vol, out, ref
+    print(f"decoder on recycled volume addresses {[hex(p) for p in ptrs]}: relative error vs the fp32 kernel {errs}")
+    assert max(errs) <= 2e-5
+
+
+def _write_synthetic_dataset(path, n_samples, rng):
+    """a garmentnets dataset store in the reference's layout (datasets/conv_implicit_wnf_dataset.py:134-181 reads it): per sample
+    point_cloud/{point,nocs,rgb,sizes}, mesh/{cloth_verts,cloth_nocs_verts,cloth_faces_tri}, marching_cube_mesh/{marching_cube_verts,
+    marching_cube_faces,is_vertex_on_surface} + attrs; summary/cloth_aabb_union"""
+    from garmentnets_amd.io import zarr_store
+    root = zarr_store.open_group(path)
+    root.require_group("summary").array("cloth_aabb_union", np.array([[-0.4, -0.4, -0.9], [0.4, 0.4, 0.05]], dtype=np.float32))
+    keys = []
+    for i in range(n_samples):
+        key = f"{i:05d}_Dress_{i:06d}_0"
+        keys.append(key)
+        sg = root.require_group("samples").require_group(key)
+        sg.put_attrs({"scale": 1.0 + 0.1 * i, "gender": i % 2, "sample_id": f"{i:05d}_Dress", "garment_name": "Dress", "grip_vertex_idx": 3 + i})
+        x, pos, _ = S.synthetic_cloud(1, 2400, seed=70 + i)
+        pos = pos.numpy()
+        nocs = ((pos - pos.min(0)) / (pos.max(0) - pos.min(0))).astype(np.float32)
+        pc, mesh, mc = sg.require_group("point_cloud"), sg.require_group("mesh"), sg.require_group("marching_cube_mesh")
+        pc.array("point", pos, chunks=(1000, 3), compressor=("zlib", 1))
+        pc.array("nocs", nocs)
+        pc.array("rgb", (x.numpy() * 255).astype(np.uint8))
+        pc.array("sizes", np.array([600, 600, 600, 600], dtype=np.int64))
+        mesh.array("cloth_verts", pos[:300].astype(np.float32))
+        mesh.array("cloth_nocs_verts", nocs[:300])
+        mesh.array("cloth_faces_tri", rng.integers(0, 300, (500, 3)).astype(np.int32))
+        mc.array("marching_cube_verts", rng.random((700, 3)).astype(np.float32), chunks=(256, 3), compressor=("zlib", 1))
+        mc.array("marching_cube_faces", rng.integers(0, 700, (1300, 3)).astype(np.int32))
+        mc.array("is_vertex_on_surface", rng.random(700) > 0.4)
+    return keys
+
+
+def _zarr_v2_read(store, path):
+    """independent minimal Zarr v2 reader (spec only; shares no code with garmentnets_amd.io.zarr_store)"""
+    import itertools
+    import zlib
+    base = os.path.join(store, path)
+    meta = json.load(open(os.path.join(base, ".zarray")))
+    assert meta["zarr_format"] == 2 and meta["order"] == "C" and not meta.get("filters")
+    shape, chunks, dt = meta["shape"], meta["chunks"], np.dtype(meta["dtype"])
+    out = np.full(shape, meta["fill_value"] if meta["fill_value"] is not None else 0, dtype=dt)
+    for idx in itertools.product(*[range(max(1, -(-s // c))) for s, c in zip(shape, chunks)]):
+        f = os.path.join(base, ".".join(str(i) for i in idx) if idx else "0")
+        if not os.path.exists(f):
+            continue
+        raw = open(f, "rb").read()
+        if meta["compressor"] is not None:
+            assert meta["compressor"]["id"] == "zlib"
+            raw = zlib.decompress(raw)
+        chunk = np.frombuffer(raw, dtype=dt).reshape(chunks)
+        sel = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
+        out[sel] = chunk[tuple(slice(0, s.stop - s.start) for s in sel)]
+    return out
+
+
+def test_predict_main_writes_the_store_eval_reads(tmp_path):
+    """f1 end to end: predict.main over a small dataset store (rotation augmentation ON as in predict_default.yaml, static seed) ->
+    prediction.zarr, read back with an independent Zarr v2 reader along EVERY key eval.py touches (eval.py:58-70,106-110,147-152,
+    193-208): marching_cubes_mesh/*, point_cloud/{gt_nocs,pred_nocs,...}, misc/{gt_nocs_grip_point,...}, gt_marching_cubes_mesh/* (copy of
+    the input sample's marching_cube_mesh), gt_mesh/* (cloth_verts rotated by the sample's augmentation matrix), per-sample attrs
+    (predict.py:120-136) and the root `subset` attr -- and against predict_batch on the same dataset items"""
+    from garmentnets_amd import predict as PR
+    from garmentnets_amd.io.dataset import GarmentInputDataset
+    rng = np.random.default_rng(5)
+    din, dout = str(tmp_path / "garmentnets_dataset.zarr"), str(tmp_path / "prediction.zarr")
+    keys = _write_synthetic_dataset(din, 2, rng)
+    PR.main(["--zarr_in", din, "--zarr_out", dout, "--num_samples", "2", "--num_pc_sample", "1800", "--num_views", "3", "--grid", "16", "--volume_size", "24",
+             "--auto_level", "--static_epoch_seed", "--random_rot_range", "-180", "180", "--subset", "test"])
+    assert json.load(open(os.path.join(dout, ".zattrs")))["subset"] == "test"
+    ds = GarmentInputDataset(din, num_pc_sample=1800, num_views=3, static_epoch_seed=True, enable_augumentation=True, random_rot_range=(-180, 180))
+    hp = S.default_hparams(grid=16, reduce_method="max")
+    model = _model(hp, 0)
+    for i, key in enumerate(keys):
+        base = os.path.join("samples", key)
+        attrs = json.load(open(os.path.join(dout, base, ".zattrs")))
+        assert attrs == {"scale": 1.0 + 0.1 * i, "gender": i % 2, "sample_id": f"{i:05d}_Dress", "garment_name": "Dress", "grip_vertex_idx": 3 + i, "batch_idx": i}
+        item = ds[i]
+        data = GarmentInputDataset.collate([item])
+        rot = item["input_aug_rot_mat"][0]
+        assert not np.allclose(rot, np.eye(3))
+        res = PR.to_host(predict_batch(model, data.to(DEV), volume_size=24, auto_level=True)[0])
+        rd = lambda *p: _zarr_v2_read(dout, os.path.join(base, *p))
+        # eval.py:67-70,195-198: the predicted mesh
+        for k in ("verts", "faces", "normals", "volume_value", "volume_gradient_magnitude", "warp_field"):
+            got = rd("marching_cubes_mesh", k)
+            assert got.dtype == res[k].dtype and np.array_equal(got, res[k]), k
+        assert rd("marching_cubes_mesh", "verts").shape[0] > 50
+        # eval.py:108-110, predict.py:220-227
+        assert np.array_equal(rd("point_cloud", "gt_nocs"), item["y"]) and rd("point_cloud", "gt_nocs").dtype == np.float32
+        assert rd("point_cloud", "pred_nocs").shape == (1800, 3) and rd("point_cloud", "pred_nocs_logits").shape == (1800, 192)
+        assert np.array_equal(rd("point_cloud", "input_points"), item["pos"]) and rd("point_cloud", "input_rgb").dtype == np.uint8
+        assert rd("point_cloud", "pred_nocs_confidence").shape == (1800, 3)
+        # eval.py:149-152, predict.py:268-274
+        assert np.array_equal(rd("misc", "gt_nocs_grip_point"), item["nocs_grip_point"][0])
+        for k, shp in (("pred_nocs_grip_point", (3,)), ("pred_global_nocs_grip_point", (3,)), ("pred_global_confidence", (64, 3)), ("global_feature", (1024,))):
+            assert rd("misc", k).shape == shp, k
+        # eval.py:62-65,205-208, predict.py:236-239: copy of the input group
+        for k in ("marching_cube_verts", "marching_cube_faces", "is_vertex_on_surface"):
+            src = _zarr_v2_read(din, os.path.join(base, "marching_cube_mesh", k))
+            got = rd("gt_marching_cubes_mesh", k)
+            assert got.dtype == src.dtype and np.array_equal(got, src), k
+        # eval.py:200-203, predict.py:241-250: gt_mesh with the augmentation rotation on cloth_verts
+        cv = _zarr_v2_read(din, os.path.join(base, "mesh", "cloth_verts"))
+        assert np.array_equal(rd("gt_mesh", "cloth_verts"), cv @ rot.T)
+        for k in ("cloth_nocs_verts", "cloth_faces_tri"):
+            assert np.array_equal(rd("gt_mesh", k), _zarr_v2_read(din, os.path.join(base, "mesh", k))), k
+
+
+def test_two_process_bench_on_one_gpu():
+    """the N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU: two
+    ranks share cuda:0 and exchange their metrics over gloo (GARMENTNETS_DIST_BACKEND=gloo; RCCL needs one device per rank).  The line
+    must see both ranks, the global batch must be the two shards, and the per-garment result checksums, in rank order, must equal what
+    each shard gives in THIS process (like for like: PointConv's self-loop quirk ties a garment's result to its slot in the LOCAL batch)"""
+    import bench
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = dict(batch=2, points=2000, grid=32, reduce="mean", Q=32)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GARMENTNETS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(cfg["batch"]), "--points", str(cfg["points"]),
+           "--grid", str(cfg["grid"]), "--volume-size", str(cfg["Q"]), "--no-strict-pass", "--no-host-io-pass", "--no-occupancy-pass", "--no-in-flight-pass",
+           "--no-validate", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints, rank 1 does not
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["dist_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 2 and line["value"] > 0
+    assert abs(line["value"] - 4 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-6 * line["value"]
+    sums = line["garment_checksums"]
+    assert len(sums) == 4
+    want = []
+    for r in range(2):
+        hp, sd, shard, (lo, hi) = bench.bench_inputs(cfg["batch"], cfg["points"], cfg["grid"], cfg["reduce"], "planted", r, 2)
+        assert (lo, hi) == (2 * r, 2 * r + 2)
+        model = ConvImplicitWNFPipeline(**hp)
+        model.load_state_dict(sd)
+        model = model.to(DEV).eval().requires_grad_(False)
+        model.arith = model.arith.replace(sparse_first_conv=False)
+        res = predict_batch(model, shard.to(DEV), volume_size=cfg["Q"], iso_surface_level=0.5, auto_level=line["config"]["iso_level"] != 0.5)
+        want += [float(x["wnf_volume"].double().sum()) for x in res]
+    assert np.allclose(sums, want, rtol=1e-6, atol=1e-6), (sums, want)
+    assert len(set(round(v, 3) for v in sums)) == 4                 # four different garments
