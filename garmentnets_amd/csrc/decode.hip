@@ -114,13 +114,8 @@ __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict_
 // ~1.8 x 512 B.  Same arithmetic and accumulation order as tri_query (bit-identical output, checked in the tests).
 #define TB_I 4
 #define TB_J 4
-#ifndef TB_K
 #define TB_K 4
-#endif
 #define TB_Q (TB_I * TB_J * TB_K)
-#ifndef TB_ABL
-#define TB_ABL 0      // dev-only ablation switches (tools/dev/ab_sampler_abl.py)
-#endif
 
 __device__ __forceinline__ float tb_coord(int i, int Q) {
     const float sc = __fdiv_rn(1.0f, __fsub_rn((float)Q, 1.0f));
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
     }
 
     {
-        if (in_lds && !(TB_ABL & 1)) {
+        if (in_lds) {
             // stage [voxel][32 channels]: one DMA instruction per (z, y) row of the box = ex voxels x 8 16-byte pieces, lane = voxel * 8 +
             // piece (<= 48 active lanes; no integer divisions: waves take whole z planes)
             const int vx = lane >> 3, pc = lane & 7;
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                if ((okm[qn] & (1u << c)) && !(TB_ABL & 2)) {
+                if (okm[qn] & (1u << c)) {
                     const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
                     float4 v;
                     if (in_lds) v = *reinterpret_cast<const float4 *>(tb_smem + ((size_t)(vidx[qn] + (dz * ey + dy) * ex + dx) * 32 + part * 4) * 4);
@@ -207,8 +202,7 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
                     acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, wgt[qn][c]));
                     acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, wgt[qn][c]));
                 }
-            if (!(TB_ABL & 4)) *reinterpret_cast<float4 *>(out + mrow[qn] * ldo + cg * 32 + part * 4) = acc;
-            else if (acc.x == 12345.f) out[0] = acc.y;
+            *reinterpret_cast<float4 *>(out + mrow[qn] * ldo + cg * 32 + part * 4) = acc;
         }
     }
 }

@@ -880,12 +880,16 @@ extern "C" int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing
 // delete_invalid_verts (common/marching_cubes_util.py:38-52; eval.py / predict.py's hole head): keep the faces whose three vertices
 // are on the surface, keep the vertices those faces use (ascending raw index = np.unique order), renumber.  One flag word per index
 // i (low 32 bits: vertex i is used, high 32 bits: face i is kept), the three-kernel exclusive scan of the MC33 stage over the packed
-// pair, one scatter pass.  Deterministic; sizes come back in counts (device), outputs have room for everything.
+// pair, one scatter pass.  Deterministic; sizes come back in counts (device int64 [3]: vertices kept, faces kept, 1 if a face index
+// was outside [0, V)), outputs have room for everything.
+// A face index outside [0, V) (the reference's numpy indexing raises IndexError for it) never touches memory: the face is dropped and
+// bit 62 of flags[0]'s neighbour word `bad` is raised; gn_mesh_compact reports it through counts[2].
 __global__ __launch_bounds__(256) void compact_mark_kernel(const int32_t *__restrict__ faces, const unsigned char *__restrict__ on_surface,
-                                                           int64_t F, unsigned long long *__restrict__ flags) {
+                                                           int64_t V, int64_t F, unsigned long long *__restrict__ flags, unsigned *__restrict__ bad) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int32_t a = faces[3 * f], b = faces[3 * f + 1], c = faces[3 * f + 2];
+    if (a < 0 || b < 0 || c < 0 || a >= V || b >= V || c >= V) { atomicOr(bad, 1u); return; }
     if (on_surface[a] && on_surface[b] && on_surface[c]) {
         atomicOr(reinterpret_cast<unsigned *>(flags + a), 1u);
         atomicOr(reinterpret_cast<unsigned *>(flags + b), 1u);
@@ -911,14 +915,15 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const unsigned cha
     }
 }
 
-__global__ void unpack_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts) {
+__global__ void unpack_counts_kernel(const unsigned long long *__restrict__ total, const unsigned *__restrict__ bad, int64_t *__restrict__ counts) {
     counts[0] = (int64_t)(*total & 0xffffffffull);
     counts[1] = (int64_t)(*total >> 32);
+    counts[2] = (int64_t)*bad;
 }
 
 extern "C" size_t gn_mesh_compact_workspace_bytes(int64_t V, int64_t F) {
     const size_t n = (size_t)(V > F ? V : F), nb = (n + SCAN_ELEMS - 1) / SCAN_ELEMS;
-    return sizeof(unsigned long long) * (2 * n + nb + 2);
+    return sizeof(unsigned long long) * (2 * n + nb + 3);
 }
 
 extern "C" int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, const unsigned char *on_surface, int64_t V, int64_t F,
@@ -927,21 +932,23 @@ extern "C" int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t 
     GN_REQUIRE(ws_bytes >= gn_mesh_compact_workspace_bytes(V, F), "gn_mesh_compact: workspace too small");
     hipStream_t st = gn_stream(stream);
     const int64_t n = V > F ? V : F;
-    if (n == 0 || F == 0 || V == 0) {
-        GN_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st), "gn_mesh_compact");
+    if (n == 0 || F == 0) {                         // (V == 0 with faces: every index is out of range -> the bad flag below)
+        GN_HIP(hipMemsetAsync(counts, 0, 3 * sizeof(int64_t), st), "gn_mesh_compact");
         return GN_OK;
     }
     const int64_t nb = gn_cdiv(n, SCAN_ELEMS);
     unsigned long long *flags = reinterpret_cast<unsigned long long *>(ws), *ex = flags + n, *bsum = ex + n, *total = bsum + nb;
+    unsigned *bad = reinterpret_cast<unsigned *>(total + 1);
     GN_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned long long) * (size_t)n, st), "gn_mesh_compact");
-    hipLaunchKernelGGL(compact_mark_kernel, dim3((unsigned)gn_cdiv(F, 256)), dim3(256), 0, st, faces, on_surface, F, flags);
+    GN_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned long long), st), "gn_mesh_compact");
+    hipLaunchKernelGGL(compact_mark_kernel, dim3((unsigned)gn_cdiv(F, 256)), dim3(256), 0, st, faces, on_surface, V, F, flags, bad);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, (int64_t)0, (int64_t)0);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, nb, total, (int64_t)0);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, flags, n, bsum, ex, (int64_t)0, (int64_t)0);
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)gn_cdiv(n, 256)), dim3(256), 0, st, (const unsigned char *)verts, vert_bytes, faces, V, F,
                        flags, ex, (unsigned char *)out_verts, out_faces);
     // counts = (vertices kept, faces kept): unpack the scan total on the device
-    hipLaunchKernelGGL(unpack_counts_kernel, dim3(1), dim3(1), 0, st, total, counts);
+    hipLaunchKernelGGL(unpack_counts_kernel, dim3(1), dim3(1), 0, st, total, bad, counts);
     GN_LAUNCH_CHECK("gn_mesh_compact");
     return GN_OK;
 }

@@ -193,10 +193,9 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
     const int n = max_points_per_example;
     GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
     const bool lds_pos = n <= 8192;
-    const char *fenv = getenv("GARMENTNETS_FPS_THREADS");                     // dev A/B: 256 / 512 / 1024
-    const int want = fenv ? atoi(fenv) : 512;
-    const bool small = n <= 12 * 512 && want != 1024;
-    const int threads = small ? (want == 256 ? 256 : 512) : FPS_THREADS;
+    // clouds up to 6144 points: 512 threads with packed-fp32 pair updates (2.73 vs 3.01 ms at n = 6000 with 1024; 256 threads: slower)
+    const bool small = n <= 12 * 512;
+    const int threads = small ? 512 : FPS_THREADS;
     size_t sh = sizeof(float) * 4 * (threads / 64) + (lds_pos ? sizeof(float) * 3 * (size_t)n : 0);
     int ppt = (int)gn_cdiv(n, threads);
 #define FPS_LAUNCH(P, L, T)                                                                                     \
@@ -204,13 +203,7 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
         GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
         hipLaunchKernelGGL((fps_kernel<P, L, T>), dim3(B), dim3(T), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
     } while (0)
-    if (small && threads == 256) {
-        if (ppt <= 4) FPS_LAUNCH(4, true, 256);
-        else if (ppt <= 8) FPS_LAUNCH(8, true, 256);
-        else if (ppt <= 12) FPS_LAUNCH(12, true, 256);
-        else if (ppt <= 16) FPS_LAUNCH(16, true, 256);
-        else FPS_LAUNCH(24, true, 256);
-    } else if (small) {
+    if (small) {
         if (ppt <= 2) FPS_LAUNCH(2, true, 512);
         else if (ppt <= 4) FPS_LAUNCH(4, true, 512);
         else if (ppt <= 6) FPS_LAUNCH(6, true, 512);

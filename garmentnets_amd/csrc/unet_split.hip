@@ -1,5 +1,5 @@
 // unet_split.hip -- split-operand variant of the 'gcr' conv on the 16-bit matrix cores (gn_conv3d_gcr_split).  Its f16x2 mode is
-// the default conv arithmetic of garmentnets_amd (ops.CONV_MODE); unet.hip holds the plain fp32-MFMA kernel.
+// the default conv arithmetic of garmentnets_amd (arith.Arith.conv_mode); unet.hip holds the plain fp32-MFMA kernel.
 //
 // Same implicit-GEMM structure, tiling, GroupNorm-on-load, upsample/concat folding and epilogue as conv3d_gcr_kernel
 // (unet.hip), but every fp32 operand is decomposed EXACTLY into P bf16 planes (x = x1 + x2 [+ x3], xi = bf16_rn of the
@@ -33,9 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SP_HX (SP_TX + 2)
 #define SP_HVOX (SP_HZ * SP_HY * SP_HX)
 #define SP_KS 16
-#ifndef SP_ABL
-#define SP_ABL 0     // dev-only ablation switches (tools/dev/ab_split_abl.py); 0 in the product build
-#endif
 
 // border class of coordinate z on an axis of length D for reach r (see SplitArgs::kreach)
 __device__ __forceinline__ int sp_axis_class(int z, int D, int r) { return z < r ? z : (z >= D - r ? 2 * r - (D - 1 - z) : r); }
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     for (int s = 0; s < nslices; ++s) {
         const int c0 = s * SP_KS;
         // (every halo read of the previous slice completed before its last tap's barrier: the halo can be overwritten)
-        if (PRE && (!(SP_ABL & 2) || s == 0)) {
+        if (PRE) {
             const bool from1 = c0 >= p.C0;
             const int c4 = (tid & 3) * 4;
             const float *base = (from1 ? p.src1 + (int64_t)b * D1 * H1 * W1 * p.C1 + (c0 - p.C0) : p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0 + c0) + c4;
@@ -274,9 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                     for (int i = 0; i < P; ++i) *reinterpret_cast<uint2 *>(halo + lo + i * 32) = pl[i];
                 }
             }
-        } else
-        if (!(SP_ABL & 2) || s == 0)
-        {   // ---- halo stage: GroupNorm affine, then exact split into P bf16 planes.  All the tile's loads are issued before the
+        } else {   // ---- halo stage: GroupNorm affine, then exact split into P bf16 planes.  All the tile's loads are issued before the
             //      first use (one exposed latency per slice), the other workgroup of the CU computes meanwhile
             const bool from1 = c0 >= p.C0;
             const float *src = from1 ? p.src1 : p.src0;
@@ -354,11 +349,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 for (int i = 0; i < P; ++i) bf[u][i] = nbf[u][i];
             // hand-over: every wave holds step j's fragments in registers (lgkmcnt(0)) and its DMA share of step j+1 has landed
             // (VM queue, oldest first: steps j+1 .. j+DEPTH-1, CH pieces each)
-            if (!(SP_ABL & 8)) {
-                GN_WAIT_VM_LGKM0((DEPTH - 2) * CH);
-                __builtin_amdgcn_s_barrier();
-            }
-            if (tap + 1 < 27 && !(SP_ABL & 4)) {
+            GN_WAIT_VM_LGKM0((DEPTH - 2) * CH);
+            __builtin_amdgcn_s_barrier();
+            if (tap + 1 < 27) {
                 const int t1 = tap + 1;
                 const int toff = HL::at(t1 / 9, (t1 / 3) % 3, t1 % 3);
 #pragma unroll
@@ -370,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
                     for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
             }
-            if (!(SP_ABL & 1)) SP_ISSUE_B();        // step j+DEPTH overwrites step j's slot (read by everyone before the barrier)
+            SP_ISSUE_B();                           // step j+DEPTH overwrites step j's slot (read by everyone before the barrier)
             __builtin_amdgcn_sched_barrier(0);
 #define SP_PROD(IA, IB)                                                                                                        \
             _Pragma("unroll") for (int u = 0; u < NT; ++u)                                                                     \
@@ -460,30 +453,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 // at taps 8-12, ordered by the per-tap barriers alone.  The matrix-core stream never stops for staging.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-// ZTWIN (the 32-wide layers, Cout % 64 != 0: 26 % of the step at 0.41 of the roofline in round 1): the same 8-wave machine, but the two
-// wave groups take two z-ADJACENT 4 x 8 x 8 tiles (one 8 x 8 x 8 block, ONE 10 x 10 x 10 halo: 1.95 staged voxels per output voxel
-// instead of 2.34) of the SAME 32 output channels and share every DMA'd B fragment.  What it buys over conv3d_split_kernel<1,...>:
-// the staging of slice s+1 rides inside the matrix-core stream of slice s (double-buffered halo) instead of stopping it.
-// SPW_PIPE = 1 (dev build): B fragments double-buffered one tap ahead (read right after the hand-over, consumed next tap).  The 16 extra
-// registers only fit next to a SINGLE-level accumulation (no per-slice `tot`): measured 431 vs 417.5 TFLOP/s-eq (+3.2 %) on 128 -> 128
-// at 128^3, but the error against fp64 grows from 3.4-3.8e-6 to 3.1-9.4e-6 (above the fp32-MFMA kernel's in two of five shapes) -- not
-// worth it; the product build keeps the two-level summation.
-#ifndef SPW_PIPE
-#define SPW_PIPE 0
-#endif
-template <int P, bool F16, bool ZTWIN>
+template <int P, bool F16>
 __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) {
     static_assert(P == 2, "the wide variant is sized for the two-plane modes");
-    constexpr bool PIPE = SPW_PIPE != 0, TWOLEVEL = !PIPE;
-    constexpr int NT = ZTWIN ? 1 : 2;
-    constexpr int TZ = ZTWIN ? 2 * SP_TZ : SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
-    constexpr int CW = ZTWIN ? 32 : 128;            // output channels per workgroup
+    constexpr int NT = 2;
+    constexpr int TZ = SP_TZ, HZ = TZ + 2, HVOX = HZ * SP_HY * SP_HX;
+    constexpr int CW = 128;                         // output channels per workgroup
     using HL = HaloLayout<P, HZ>;
     constexpr int HALO_BYTES = HL::BYTES;
-    constexpr int NPIECE = (ZTWIN ? 1 : 2) * NT * P; // 1-KB B fragments per step: both column groups / the one shared column block
+    constexpr int NPIECE = 2 * NT * P;              // 1-KB B fragments per step: both column groups
     constexpr int BTAP = NPIECE * 1024;
-    constexpr int DEPTH = 4, CH = 1;                // one piece per wave per step (ZTWIN: the 2 pieces are fetched 4 times over, harmlessly)
-    constexpr int NIT = (HVOX * 4 + 511) / 512;     // 5 (8 for ZTWIN) row loads per thread per slice
+    constexpr int DEPTH = 4, CH = 1;                // one piece per wave per step
+    constexpr int NIT = (HVOX * 4 + 511) / 512;     // 5 row loads per thread per slice
     constexpr int AD_OFF = 2 * HALO_BYTES + DEPTH * BTAP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AD_OFF + 2 * 384 * 4];
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + 2 * HALO_BYTES;
@@ -501,8 +482,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
     const int z0 = tz * TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
-    const int n0 = ZTWIN ? cb * 32 : cb * 128 + cg * 64;
-    const int zl = ZTWIN ? zs + 4 * cg : zs;        // this wave's z-slice inside the tile
+    const int n0 = cb * 128 + cg * 64;
+    const int zl = zs;                              // this wave's z-slice inside the tile
     const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
     const int nslices = Cin / SP_KS;
@@ -520,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     for (int i = tid; i < Cin; i += 512) { adl[i] = p.a[(int64_t)b * Cin + i]; adl[384 + i] = p.d[(int64_t)b * Cin + i]; }
 
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
-    const int piece = ZTWIN ? (wave & (NPIECE - 1)) : wave;
+    const int piece = wave;
     const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + piece * 1024 + lane * 16;
     int jf = 0;
 #define SPW_ISSUE_B()                                                                                                          \
@@ -560,7 +541,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[it]) : "v"(voff[it] + cb4), "s"(base0) : "memory");
             return;
         }
-        // the half-resolution (nearest-upsampled) source: only reached with ops.POLYPHASE_UPCONV off; offsets re-derived per slice
+        // the half-resolution (nearest-upsampled) source: only reached with Arith.polyphase_upconv off; offsets re-derived per slice
         const int cs = c0 - p.C0;
         inb = 0;
         int tl = tid;
@@ -613,13 +594,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 
     const int abase = HL::at(zl, r >> 3, r & 7) + 16 * h;
     constexpr int AF1 = 4 * HL::ROWP;
-    const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + (ZTWIN ? 0 : cg * NT * P) * 1024 + lane * 16;
+    const unsigned char *const ring_rd = smem + 2 * HALO_BYTES + cg * NT * P * 1024 + lane * 16;
     int jcur = 0;
-    uint4 bf[NT][P], nbf[NT][P];                    // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
+    uint4 bf[NT][P];                                // step 0's fragments (the prologue DMAs were drained with the slice-0 staging)
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int i = 0; i < P; ++i) nbf[u][i] = bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (u * P + i) * 1024);
+        for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (u * P + i) * 1024);
     for (int s = 0; s < nslices; ++s) {
         const unsigned char *const halo = smem + (s & 1) * HALO_BYTES;
         const int sn = s + 1 < nslices ? s + 1 : s;
@@ -633,12 +614,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
         for (int tap = 0; tap < 27; ++tap, ++jcur) {
 #pragma unroll
             for (int i = 0; i < P; ++i) { a0[i] = na0[i]; a1[i] = na1[i]; }
-            if (PIPE) {
-#pragma unroll
-                for (int u = 0; u < NT; ++u)
-#pragma unroll
-                    for (int i = 0; i < P; ++i) bf[u][i] = nbf[u][i];
-            }
             // hand-over: step j+1's fragments have landed for everybody (they are read at the END of this tap, into the registers the
             // MFMAs of this tap have just consumed: no register double buffer, no LDS latency after the barrier) and everybody is done
             // with step j-1's slot.  VM queue, oldest first: fragment steps j+1 .. j+DEPTH-2 and, for taps 1-2, the NIT row loads
@@ -647,24 +622,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             //  waits for each of them right before the MFMA that consumes it; a blanket lgkmcnt(0) here would expose their LDS
             //  latency at every barrier.  The slot the DMA below overwrites, step j-1's, was consumed by MFMAs every wave has issued.
             //  Tap 26 drains the LDS queue once per slice so that the staged rows of the next slice are visible after its barriers.)
-            if (!ZTWIN) {
-                if (tap == 26) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
-                else if (tap >= 1 && tap <= 2) GN_WAIT_VM_ONLY((DEPTH - 3) * CH + NIT);
-                else GN_WAIT_VM_ONLY((DEPTH - 3) * CH);
-                __builtin_amdgcn_s_barrier();
-                SPW_ISSUE_B();                      // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
-            } else if ((tap & 1) == 0) {
-                // ZTWIN: a wave has only 6 MFMAs per tap, so the hand-over (wait + barrier + DMA issue) is paid once per PAIR of taps
-                // (0,1) ... (24,25), (26): step j is in registers, steps j+1 and j+2 (issued one hand-over ago) must have landed --
-                // everything outstanding except the NIT row loads issued after the hand-over of tap 0 -- and the slots of steps
-                // j-1 and j are free for steps j+3 and j+4 (tap 26 is alone: one step)
-                if (tap == 26) GN_WAIT_VM_LGKM0(0);
-                else if (tap == 2) GN_WAIT_VM_ONLY(NIT);
-                else GN_WAIT_VM_ONLY(0);
-                __builtin_amdgcn_s_barrier();
-                SPW_ISSUE_B();
-                if (tap < 26) SPW_ISSUE_B();
-            }
+            if (tap == 26) GN_WAIT_VM_LGKM0((DEPTH - 3) * CH);
+            else if (tap >= 1 && tap <= 2) GN_WAIT_VM_ONLY((DEPTH - 3) * CH + NIT);
+            else GN_WAIT_VM_ONLY((DEPTH - 3) * CH);
+            __builtin_amdgcn_s_barrier();
+            SPW_ISSUE_B();                          // step j+DEPTH-1 -> the slot step j-1 vacated one tap ago
             if (tap + 1 < 27) {
                 const int t1 = tap + 1;
                 const int toff = HL::at(t1 / 9, (t1 / 3) % 3, t1 % 3);
@@ -673,12 +635,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                     na0[i] = *reinterpret_cast<const uint4 *>(halo + abase + toff + i * 32);
                     na1[i] = *reinterpret_cast<const uint4 *>(halo + abase + AF1 + toff + i * 32);
                 }
-            }
-            if (PIPE) {          // step j+1 landed for everybody before this tap's hand-over: fetch it now, a whole tap before its MFMAs
-#pragma unroll
-                for (int u = 0; u < NT; ++u)
-#pragma unroll
-                    for (int i = 0; i < P; ++i) nbf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
             }
             if (tap == 0) issue_rows(sn);                                        // always (uniform wait counts); unused after the last slice
             __builtin_amdgcn_sched_barrier(0);
@@ -692,22 +648,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             SPW_PROD(0, 1) SPW_PROD(0, 0)
 #undef SPW_PROD
             __builtin_amdgcn_sched_barrier(0);
-            if (!PIPE) {
 #pragma unroll
-                for (int u = 0; u < NT; ++u)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-                    for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int i = 0; i < P; ++i) bf[u][i] = *reinterpret_cast<const uint4 *>(ring_rd + ((jcur + 1) & (DEPTH - 1)) * BTAP + (u * P + i) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (TWOLEVEL) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < NT; ++u)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
-        }
+                for (int q = 0; q < 16; ++q) { tot[t][u][q] = __fadd_rn(tot[t][u][q], acc[t][u][q]); acc[t][u][q] = 0.f; }
     }
 #undef SPW_ISSUE_B
     GN_WAIT_VM_LGKM0(0);
@@ -728,7 +680,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 const int gy = y0 + t * 4, gx = x0 + 4 * h;
                 float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n;
                 const float *pb = p.partial ? p.partial + ((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((gz & 1) * 4 * p.Cout + n) : nullptr;
-                sp_store_frag_full(p, TWOLEVEL ? tot[t][u] : acc[t][u], osc, ob, pb, ssum[u], ssq[u]);
+                sp_store_frag_full(p, tot[t][u], osc, ob, pb, ssum[u], ssq[u]);
                 continue;
             }
 #pragma unroll
@@ -742,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                         const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
-                        v = __fmul_rn(TWOLEVEL ? tot[t][u][q] : acc[t][u][q], osc);
+                        v = __fmul_rn(tot[t][u][q], osc);
                         if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
@@ -752,19 +704,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 }
             }
         }
-    if (p.osum && ZTWIN) {
-        float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][wave][32]
-        const float s2 = ssum[0] + __shfl_xor(ssum[0], 32), q2 = ssq[0] + __shfl_xor(ssq[0], 32);
-        if (h == 0) { red[wave * 32 + r] = s2; red[256 + wave * 32 + r] = q2; }
-        __syncthreads();
-        if (tid < 32) {
-            double s8 = 0.0, q8 = 0.0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { s8 += (double)red[w * 32 + tid]; q8 += (double)red[256 + w * 32 + tid]; }
-            atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s8);
-            atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q8);
-        }
-    } else if (p.osum) {
+    if (p.osum) {
         float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][cg][zs][64]
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -781,16 +721,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
             atomicAdd(&p.osq[(int64_t)b * p.Cout + cb * 128 + tid], q4);
         }
     }
-}
-
-// The z-twin variant is OFF by default: measured on MI355X (B=16, 128^3, the three 32-wide layers) it reaches 315 (one hand-over per
-// tap) / 323 (one per tap pair) TFLOP/s-equivalent against 331-344 for conv3d_split_kernel<1,...> with its synchronous staging and two
-// independent workgroups per CU.  A 32-wide layer does 3.3x the staging work per MFMA of a 128-wide one whatever the tiling (16 MFMA
-// k-steps per staged voxel-slice instead of 55): hiding the staging does not remove its issue slots.  GARMENTNETS_ZTWIN=1 selects it
-// for A/B runs.
-static bool gn_ztwin_enabled() {
-    static const bool on = [] { const char *e = getenv("GARMENTNETS_ZTWIN"); return e && e[0] == '1'; }();
-    return on;
 }
 
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
@@ -838,17 +768,10 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
-    // z-twin variant: the 32-wide layers (Cout not a multiple of 64) with enough 8 x 8 x 8 blocks to fill the chip twice
-    const int tiles8 = (int)gn_cdiv(D, 2 * SP_TZ) * p.tiles_y * p.tiles_x;
-    const bool ztwin = mode != GN_SPLIT_BF16X3 && Cout % 64 != 0 && Cin_total <= 384 && fits32 && (int64_t)tiles8 * (Cout / 32) * B >= 512 && gn_ztwin_enabled();
     if (wide128) {
-        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
-        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, false>" : "conv3d_split_wide_kernel<2, false, false>");
-    } else if (ztwin) {
-        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true, true>), dim3(tiles8 * (Cout / 32), B), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false, true>), dim3(tiles8 * (Cout / 32), B), dim3(512), 0, st, p);
-        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true, true>" : "conv3d_split_wide_kernel<2, false, true>");
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true>" : "conv3d_split_wide_kernel<2, false>");
     } else
     if (mode == GN_SPLIT_BF16X3) SP_LAUNCH(3, false);
     else if (mode == GN_SPLIT_BF16X2) SP_LAUNCH(2, false);

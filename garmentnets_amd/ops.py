@@ -677,9 +677,16 @@ def scale_verts(verts_vox, spacing):
 
 
 def mesh_compact(verts, faces, on_surface):
-    """delete_invalid_verts on the GPU -> (verts' (V',3) same dtype, faces' (F',3) int32); one host synchronisation for the two sizes"""
+    """delete_invalid_verts on the GPU -> (verts' (V',3) same dtype, faces' (F',3) int32); one host synchronisation for the two sizes.
+    A face index outside [0, V) raises IndexError, as the reference's numpy indexing does (common/marching_cubes_util.py:41)."""
     assert verts.dim() == 2 and verts.shape[1] == 3 and verts.dtype in (torch.float32, torch.float64)
     verts = verts.contiguous()
+    if faces.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"faces: expected an integer tensor, got {faces.dtype}")
+    if verts.shape[0] >= 2 ** 31:
+        raise ValueError("mesh_compact: more than 2^31 vertices")
+    if faces.dtype == torch.int64:          # int32 on the device; an index that does not fit is out of range for any V < 2^31: keep it so
+        faces = faces.clamp(min=-1, max=2 ** 31 - 1)
     faces = _chk(faces.to(torch.int32).contiguous(), torch.int32, "faces")
     flag = on_surface.to(torch.uint8).contiguous()
     V, F = verts.shape[0], faces.shape[0]
@@ -688,9 +695,11 @@ def mesh_compact(verts, faces, on_surface):
     nbytes = _lib.load().gn_mesh_compact_workspace_bytes(V, F)
     ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=verts.device)
     out_v, out_f = torch.empty_like(verts), torch.empty_like(faces)
-    counts = torch.empty(2, dtype=torch.int64, device=verts.device)
+    counts = torch.empty(3, dtype=torch.int64, device=verts.device)
     _lib.call("gn_mesh_compact", _p(verts), verts.element_size() * 3, _p(faces), _p(flag), V, F, _p(ws), nbytes, _p(out_v), _p(out_f), _p(counts), _stream())
-    nv, nf = [int(c) for c in counts.cpu()]
+    nv, nf, bad = [int(c) for c in counts.cpu()]
+    if bad:
+        raise IndexError(f"delete_invalid_verts: a face index is out of bounds for {V} vertices")
     return out_v[:nv], out_f[:nf]
 
 

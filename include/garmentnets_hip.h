@@ -285,7 +285,8 @@ int gn_scale_verts(const float *verts_vox, int64_t nv, double spacing, float *ve
 /* Mesh compaction = delete_invalid_verts (common/marching_cubes_util.py:38-52; the hole-prediction head of predict.py:202-209 and
  * eval.py:39): keep the faces whose three vertices are flagged on_surface, keep the vertices those faces use in ascending raw index
  * (np.unique order), renumber the faces.  verts: [V][3] of vert_bytes / 3 byte scalars (12 = float32, 24 = float64); faces [F][3]
- * int32; on_surface [V] bytes (0 / non-0).  out_verts / out_faces must hold V / F rows; counts (device int64[2]) = kept (V', F'). */
+ * int32; on_surface [V] bytes (0 / non-0).  out_verts / out_faces must hold V / F rows; counts (device int64[3]) = kept (V', F') and a flag:
+ * 1 if some face index was outside [0, V) (numpy raises IndexError there; such a face is dropped without touching memory). */
 size_t gn_mesh_compact_workspace_bytes(int64_t V, int64_t F);
 int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, const unsigned char *on_surface, int64_t V, int64_t F,
                     void *ws, size_t ws_bytes, void *out_verts, int32_t *out_faces, int64_t *counts, void *stream);
