@@ -206,19 +206,19 @@ class HbmMembers:
 
     def install(self):
         nb = lambda t: t.numel() * t.element_size()
-        self._wrap("zeroed_volume", lambda out, *a, **k: nb(out[0]) + nb(out[1]))
-        self._wrap("grid_scatter", lambda out, src, flat, *a, **k: 2 * nb(src) + nb(flat))
-        self._wrap("maxpool3d_2", lambda out, x, *a, **k: nb(x) + nb(out[0] if isinstance(out, tuple) else out))
+        self._wrap("zeroed_volume", lambda res, *a, **k: nb(res[0]) + nb(res[1]))
+        self._wrap("grid_scatter", lambda res, src, flat, *a, **k: 2 * nb(src) + nb(flat))
+        self._wrap("maxpool3d_2", lambda res, x, *a, **k: nb(x) + nb(res[0] if isinstance(res, tuple) else res))
 
-        def samp(out, vol_b, query=None, Q=0, m0=0, M=None, **k):
+        def samp(res, vol_b, query=None, Q=0, m0=0, M=None, **k):
             rows = query.shape[0] if query is not None else M
             frac = 1.0 if query is not None or not Q else rows / float(Q) ** 3
             return rows * vol_b.shape[-1] * 4 + frac * nb(vol_b)
         self._wrap("trilinear_sample", samp)
-        self._wrap("ggm3d_batch", lambda out, vols, *a, **k: 2 * nb(vols))
-        self._wrap("minmax_batch", lambda out, vols, *a, **k: nb(vols))
-        self._wrap("mc33_batch", lambda out, vols, *a, **k: nb(vols))          # + V * 28 + F * 12, added in summary()
-        self._wrap("gather_nn_batch", lambda out, vols, verts, *a, **k: nb(verts) + nb(out))
+        self._wrap("ggm3d_batch", lambda res, vols, *a, **k: 2 * nb(vols))
+        self._wrap("minmax_batch", lambda res, vols, *a, **k: nb(vols))
+        self._wrap("mc33_batch", lambda res, vols, *a, **k: nb(vols))          # (+ V * 28 + F * 12 of mesh output: < 1 % of the volume bytes)
+        self._wrap("gather_nn_batch", lambda res, vols, verts, *a, **k: nb(verts) + nb(res))
 
     def uninstall(self):
         from garmentnets_amd import ops
@@ -442,7 +442,7 @@ def main():
     from garmentnets_amd.arith import Arith
     from garmentnets_amd.batch import Batch
     from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
-    from garmentnets_amd.predict import PredictJob, predict_batch, to_host
+    from garmentnets_amd.predict import PredictJob, predict_batch, to_host_batch
 
     # the global batch of batch x world garments (one seed), sharded contiguously: this rank owns garments [lo, hi)
     global_batch = args.batch * world
@@ -474,7 +474,7 @@ def main():
         res = step(host_data.to(dev, non_blocking=True))
         if args.workload == "pointnet2":
             return {k: v.cpu() for k, v in res.items() if torch.is_tensor(v)}
-        return [to_host(r) for r in res]
+        return to_host_batch(res)
 
     pipelined = [False]                              # set below: --pipeline-depth 2, full workload, fixed iso level
 

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgarmentnets_hip.so")
+# GARMENTNETS_HIP_LIB: another build of the same C ABI (deployment layouts; A/B runs of two builds in two processes)
+LIB_PATH = os.environ.get("GARMENTNETS_HIP_LIB") or os.path.join(_HERE, "libgarmentnets_hip.so")
 
 GN_OK, GN_EINVAL, GN_ELAUNCH, GN_ECAP = 0, -1, -2, -3
 

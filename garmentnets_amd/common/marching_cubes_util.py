@@ -66,12 +66,15 @@ class IsoBatchJob:
     padded buffers, and returns at once; ``finish()`` fetches the B (min, max, #verts, #faces) records in ONE device-to-host copy and
     slices the batch's buffers.  All outputs are this job's own allocations (two jobs in flight never share a buffer)."""
 
-    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent"):
+    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent", cap_v=None):
+        """cap_v: vertex capacity per volume (None: 6 Q^2, enough for a garment-like closed surface); a volume that needs more is redone
+        on its own in finish() -- a caller that sees such volumes regularly passes what the last batch needed (predict._iso_capacity)"""
         if gradient_direction not in ("ascent", "descent"):
             raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % gradient_direction)
         self.Q, self.level, self.sigma, self.direction = int(Q), float(iso_surface_level), float(sigma), gradient_direction
-        self.cap_v = max(4096, int(6 * self.Q ** 2))
+        self.cap_v = max(4096, int(6 * self.Q ** 2), int(cap_v or 0))
         self.cap_f = 2 * self.cap_v + 64
+        self.need_v = 0                              # after finish(): the largest vertex / half face count any volume of the batch asked for
         self.vols, self.ggms, self.mcs, self.recs = [], [], [], []
         self.padded, self.max_nv = [], 0             # the (Bp, cap_v, 3) float32 query buffers; largest vertex count of the batch
 
@@ -80,13 +83,6 @@ class IsoBatchJob:
         if Bp == 0:
             return
         vols = wnf_part.float().contiguous()
-        if (self.Q ** 3) % 4 != 0:                   # gn_minmax_batch reads float4s: odd lattices go garment by garment in finish()
-            for i in range(Bp):
-                self.vols.append(vols[i])
-                self.ggms.append(None)
-                self.mcs.append(None)
-                self.recs.append(None)
-            return
         ggm = ops.ggm3d_batch(vols, self.sigma)
         mc = ops.mc33_batch(vols, self.level, self.cap_v, self.cap_f)           # verts, faces, normals, values, counts (device)
         rec = torch.cat((ops.minmax_batch(vols).double(), mc[4].double()), dim=1)
@@ -106,19 +102,12 @@ class IsoBatchJob:
         """-> list of B entries, each a mesh dict or the exception (ValueError / RuntimeError) scikit-image would have raised"""
         if not self.vols:
             return []
-        have = [r for r in self.recs if r is not None]
-        host = torch.stack(have).cpu().numpy() if have else None       # the one synchronisation
+        host = torch.stack(self.recs).cpu().numpy()                    # the one synchronisation
         level = self.level
-        out, row = [], 0
+        out = []
         for b in range(len(self.vols)):
-            if self.recs[b] is None:
-                try:
-                    out.append(wnf_to_mesh_gpu(self.vols[b], level, self.sigma, self.direction))
-                except (ValueError, RuntimeError) as e:
-                    out.append(e)
-                continue
-            vmin, vmax, nv, nf = float(host[row, 0]), float(host[row, 1]), int(host[row, 2]), int(host[row, 3])
-            row += 1
+            vmin, vmax, nv, nf = float(host[b, 0]), float(host[b, 1]), int(host[b, 2]), int(host[b, 3])
+            self.need_v = max(self.need_v, nv, (nf + 1) // 2)
             if level < vmin or level > vmax:
                 out.append(ValueError("Surface level must be within volume data range."))
                 continue

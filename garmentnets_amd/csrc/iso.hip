@@ -118,20 +118,27 @@ extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, 
 // ================================================================================================ min / max
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out_enc) {
     __shared__ float smn[4], smx[4];
-    x += (int64_t)blockIdx.y * n;                   // batched: n elements and one (min, max) pair per blockIdx.y (n % 4 == 0 when batched)
+    x += (int64_t)blockIdx.y * n;                   // batched: n elements and one (min, max) pair per blockIdx.y
     out_enc += 2 * blockIdx.y;
     float mn = 3.4e38f, mx = -3.4e38f;
-    const int64_t n4 = n >> 2;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    // a volume may start anywhere (a slice of an odd-sized batch): scalar head up to the first 16-byte boundary, float4 body, scalar tail
+    int64_t head = (int64_t)(((16u - (unsigned)((uintptr_t)x & 15u)) & 15u) >> 2);
+    if (head > n) head = n;
+    const int64_t n4 = (n - head) >> 2, tail0 = head + (n4 << 2);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = x4[i];
         mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
         mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const float v = x[(n4 << 2) + threadIdx.x];
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const int64_t i = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + (threadIdx.x - 4);
+        const bool ok = threadIdx.x < 4 ? (int64_t)threadIdx.x < head : i < n;
+        if (ok) {
+            const float v = x[i];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
     }
     for (int off = 32; off >= 1; off >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, off));
@@ -162,12 +169,11 @@ __global__ void minmax_decode_kernel(unsigned *o) {
 
 extern "C" int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2, void *stream) {
     GN_REQUIRE(n > 0 && batch >= 0 && batch <= 65535, "gn_minmax: empty input");
-    GN_REQUIRE(batch <= 1 || (n & 3) == 0, "gn_minmax_batch: n must be a multiple of 4 for batch > 1");
     if (batch == 0) return GN_OK;
     hipStream_t st = gn_stream(stream);
     unsigned *o = reinterpret_cast<unsigned *>(out2);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(batch), dim3(1), 0, st, o);
-    GN_REQUIRE(((uintptr_t)x & 15) == 0, "gn_minmax: x must be 16-byte aligned");
+    GN_REQUIRE(((uintptr_t)x & 3) == 0, "gn_minmax: x must be 4-byte aligned");
     int blocks = (int)(gn_cdiv(n, 1024) < 512 ? gn_cdiv(n, 1024) : 512);
     hipLaunchKernelGGL(minmax_kernel, dim3(blocks, batch), dim3(256), 0, st, x, n, o);
     hipLaunchKernelGGL(minmax_decode_kernel, dim3(batch), dim3(1), 0, st, o);

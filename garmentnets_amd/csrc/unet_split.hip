@@ -444,6 +444,237 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 32-wide "x-strip" variant (P = 2)
+// The 32-wide layers (enc0c2 128 -> 32, dec2c1, dec2c2 at full resolution: 23 % of the step in round 2) through conv3d_split_kernel<1>
+// read 6 KB of LDS fragments per 6 MFMAs -- one B fragment pair and one A fragment pair per tap serve a single 32-wide column block, so
+// the LDS port is as busy as the matrix pipe (PMC: 8.5 LDS instructions per 512 MFMA-Mops, pipe 0.52 busy).  Here a wave's 32 fragment
+// rows are the (z, y) positions of a 4 x 8 patch at ONE x, and the x direction lives in REGISTERS: for a (dz, dy) pair the wave loads a
+// strip of 4 + 2 x-consecutive voxels once (6 x 2 planes) and the three dx taps' B fragments (3 x 2 planes), then runs the 4 x 3 x 3 = 36
+// MFMAs of its four output x positions from registers -- 18 ds_read_b128 per 36 MFMAs instead of 36, one hand-over barrier per THREE taps
+// instead of one per tap.  Per accumulator the products arrive in exactly the order of conv3d_split_kernel (taps ascending, planes
+// (1,0) (0,1) (0,0), per-slice flush into `tot`): the results are BIT-IDENTICAL to it.
+//   workgroup = 4 waves = 8 x 8 x 8 output voxels x 32 channels: wave w -> z half (w & 1), x half (w >> 1); halo 10 x 10 x 10 voxels
+//   (1.95 staged voxels per output voxel instead of 2.34), two workgroups per CU (80 KB of LDS each).
+//   LDS halo: voxel = 64 B (2 planes x 16 halfs), row pitch 656 B, z pitch 6784 B: with rows r = (zr, yr) the 16-lane service groups of
+//   ds_read_b128 hit 16 distinct bank quads (row pitch = 9, z pitch = 8 quads mod 16; enumerated over the real lane groups).
+//   B ring: two (dz, dy) groups of 6 KB; group G+1 is DMA'd right after the hand-over of group G.
+struct StripLayout {
+    static constexpr int VB = 64, RP = 10 * 64 + 16, ZP = 10 * RP + 224, HZ = 10, HY = 10, HX = 10, HVOX = 1000;
+    static constexpr int BYTES = HZ * ZP;
+    __device__ static constexpr __forceinline__ int at(int hz, int hy, int hx) { return hz * ZP + hy * RP + hx * VB; }
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p) {
+    constexpr int P = 2, T = 8, NX = 4;
+    using HL = StripLayout;
+    constexpr int HALO_BYTES = HL::BYTES;
+    constexpr int GB = 3 * P * 1024;                 // B bytes of one (dz, dy) group: 3 taps x 2 planes x 1 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HALO_BYTES + 2 * GB];
+    unsigned char *const halo = smem;
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int zw = 4 * (wave & 1), xw = NX * (wave >> 1);
+    const int Cin = p.C0;
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
+    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
+    const int ncb = p.Cout / 32;
+    int tile = (int)(logical / (unsigned)ncb);
+    const int cb = (int)(logical % (unsigned)ncb);
+    const int tiles_z = (p.D + T - 1) / T;
+    const int tz = tile % tiles_z; tile /= tiles_z;
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile;
+    const int z0 = tz * T, y0 = ty * T, x0 = tx * T;
+    const int n0 = cb * 32;
+    const int b = blockIdx.y;
+    bool inactive = false;
+    if (p.tile_active) {                             // flags are per 4 x 8 x 8 tile (gn_grid_tile_flags): this block is two of them
+        const int tz4 = (p.D + SP_TZ - 1) / SP_TZ;
+        const unsigned char *fl = p.tile_active + (int64_t)b * (tz4 * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tz4 + 2 * tz;
+        inactive = !fl[0] && !(2 * tz + 1 < tz4 && fl[1]);
+    }
+
+    f32x16s acc[NX], tot[NX];
+#pragma unroll
+    for (int t = 0; t < NX; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; tot[t][q] = 0.f; }
+
+    if (!inactive) {                                // (workgroup-uniform)
+    const int nslices = Cin / SP_KS, ngroups = nslices * 9;
+    const int64_t bstep = (int64_t)ncb * P * 1024;                                    // bytes per (slice, tap) step of the pack
+    // piece k of a group = tap 3g + (k >> 1), plane k & 1; wave w fetches pieces w and w + 4 (waves 0, 1 only)
+    const unsigned char *bg0 = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * (P * 1024) + lane * 16;
+    int G = 0;                                       // flat group index s * 9 + g of the group about to be multiplied
+    auto issue_group = [&](int g) {
+        const unsigned char *src = bg0 + (int64_t)(3 * g) * bstep;
+        const unsigned dst = lds_ring + (g & 1) * GB;
+        gn_glds16(src + (wave >> 1) * bstep + (wave & 1) * 1024, dst + wave * 1024);
+        if (wave < 2) gn_glds16(src + 2 * bstep + wave * 1024, dst + (4 + wave) * 1024);
+    };
+    issue_group(0);
+
+    const int abase = HL::at(zw + (r >> 3), r & 7, xw) + 16 * h;
+    const unsigned char *const ring_rd = smem + HALO_BYTES + lane * 16;
+    // staging: thread t owns channel quad c4 of voxels hv = (t >> 2) + 64 it, it = 0 .. 15
+    const int c4 = (tid & 3) * 4;
+    const float *const base0 = p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0 + c4;
+    for (int s = 0; s < nslices; ++s) {
+        const int c0 = s * SP_KS;
+        {
+            const float4 av = *reinterpret_cast<const float4 *>(p.a + (int64_t)b * Cin + c0 + c4);
+            const float4 dv = *reinterpret_cast<const float4 *>(p.d + (int64_t)b * Cin + c0 + c4);
+            constexpr int NIT = (HL::HVOX + 63) / 64;                                // 16
+            float4 raw[NIT];
+            unsigned inb = 0;
+            const int v0 = tid >> 2;
+            int hx = v0 % 10, hy = v0 / 10, hz = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+                const bool in = (v0 + 64 * it < HL::HVOX) && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) {
+                    raw[it] = *reinterpret_cast<const float4 *>(base0 + (int64_t)((gz * p.H + gy) * p.W + gx) * p.C0 + c0);
+                    inb |= 1u << it;
+                }
+                hx += 4; hy += 6;                    // + 64 voxels = (0, 6, 4) in (hz, hy, hx)
+                if (hx >= 10) { hx -= 10; hy += 1; }
+                if (hy >= 10) { hy -= 10; hz += 1; }
+            }
+            hx = v0 % 10; hy = v0 / 10; hz = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (v0 + 64 * it < HL::HVOX) {
+                    float v0f = 0.f, v1f = 0.f, v2f = 0.f, v3f = 0.f;
+                    if (inb & (1u << it)) {          // zero padding comes AFTER the affine
+                        v0f = __fmaf_rn(raw[it].x, av.x, dv.x);
+                        v1f = __fmaf_rn(raw[it].y, av.y, dv.y);
+                        v2f = __fmaf_rn(raw[it].z, av.z, dv.z);
+                        v3f = __fmaf_rn(raw[it].w, av.w, dv.w);
+                    }
+                    uint2 pl[P];
+                    split4<P, F16>(v0f, v1f, v2f, v3f, pl);
+                    unsigned char *dst = halo + HL::at(hz, hy, hx) + c4 * 2;
+                    *reinterpret_cast<uint2 *>(dst) = pl[0];
+                    *reinterpret_cast<uint2 *>(dst + 32) = pl[1];
+                }
+                hx += 4; hy += 6;
+                if (hx >= 10) { hx -= 10; hy += 1; }
+                if (hy >= 10) { hy -= 10; hz += 1; }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 9; ++g, ++G) {
+            // hand-over: this wave's share of group G's B fragments has landed (its only outstanding VM operations), its LDS reads of the
+            // previous group are in registers and (g == 0) its halo stores are done -> after the barrier that holds for every wave: group G
+            // is readable, slot (G + 1) & 1 is free, the halo is complete
+            GN_WAIT_VM_LGKM0(0);
+            __builtin_amdgcn_s_barrier();
+            if (G + 1 < ngroups) issue_group(G + 1);
+            uint4 bf[3][P], af[NX + 2][P];
+            const unsigned char *rb = ring_rd + (G & 1) * GB;
+            const int goff = HL::at(g / 3, g % 3, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {            // the first output position's operands first
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(halo + abase + goff + i * HL::VB + pl * 32);
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl) bf[i][pl] = *reinterpret_cast<const uint4 *>(rb + (i * P + pl) * 1024);
+            }
+#pragma unroll
+            for (int i = 3; i < NX + 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < P; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(halo + abase + goff + i * HL::VB + pl * 32);
+#pragma unroll
+            for (int xo = 0; xo < NX; ++xo)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {     // smallest terms first, as conv3d_split_kernel
+                    acc[xo] = mfma16<F16>(af[xo + dx][1], bf[dx][0], acc[xo]);
+                    acc[xo] = mfma16<F16>(af[xo + dx][0], bf[dx][1], acc[xo]);
+                    acc[xo] = mfma16<F16>(af[xo + dx][0], bf[dx][0], acc[xo]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NX; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { tot[t][q] = __fadd_rn(tot[t][q], acc[t][q]); acc[t][q] = 0.f; }
+        GN_WAIT_VM_LGKM0(0);
+        __builtin_amdgcn_s_barrier();               // every wave is done reading this slice's halo: it can be overwritten
+    }
+    }
+    __syncthreads();                                // the epilogue reuses the halo as scratch
+    // ---- epilogue: fragment xo of this wave = rows (zr = q >> 2, yr = (q & 3) + 4 h) at x = x0 + xw + xo, lane r = channel
+    float ssum = 0.f, ssq = 0.f;
+    const int n = n0 + r;
+    const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+    const bool full = !inactive && z0 + T <= p.D && y0 + T <= p.H && x0 + T <= p.W;       // (workgroup-uniform)
+    if (full) {
+        const int64_t rs = (int64_t)p.W * p.Cout, zs_ = (int64_t)p.H * rs;
+        const int gz0 = z0 + zw, gy0 = y0 + 4 * h;
+#pragma unroll
+        for (int xo = 0; xo < NX; ++xo) {
+            const int gx = x0 + xw + xo;
+            float *ob = p.out + ((((int64_t)b * p.D + gz0) * p.H + gy0) * p.W + gx) * p.Cout + n;
+            float pv[16];
+            if (p.partial) {                        // z0, y0, x0, zw, xw, 4 h are even: parity = (zr & 1, q & 1, xo & 1)
+                const int64_t prs = (int64_t)(p.W >> 1) * 8 * p.Cout, pzs = (int64_t)(p.H >> 1) * prs;
+                const float *pb = p.partial + ((((int64_t)b * (p.D >> 1) + (gz0 >> 1)) * (p.H >> 1) + (gy0 >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((xo & 1) * p.Cout + n);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int zr = q >> 2, yq = q & 3;
+                    pv[q] = pb[(zr >> 1) * pzs + (yq >> 1) * prs + (int64_t)((zr & 1) * 4 + (yq & 1) * 2) * p.Cout];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float v = __fmul_rn(tot[xo][q], osc);
+                if (p.partial) v = __fadd_rn(v, pv[q]);
+                if (p.relu) v = gn_relu(v);
+                ob[(q >> 2) * zs_ + (q & 3) * rs] = v;
+                ssum += v;
+                ssq = fmaf(v, v, ssq);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int xo = 0; xo < NX; ++xo)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int gz = z0 + zw + (q >> 2), gy = y0 + 4 * h + (q & 3), gx = x0 + xw + xo;
+                if (gz < p.D && gy < p.H && gx < p.W) {
+                    float v;
+                    if (inactive) {                  // the finished value a dense launch gives a voxel of this border class
+                        const int nc = 2 * p.kreach + 1;
+                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
+                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
+                    } else {
+                        v = __fmul_rn(tot[xo][q], osc);
+                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
+                        if (p.relu) v = gn_relu(v);
+                    }
+                    p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
+                    ssum += v;
+                    ssq = fmaf(v, v, ssq);
+                }
+            }
+    }
+    if (p.osum) {
+        float *red = reinterpret_cast<float *>(halo);
+        const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
+        if (h == 0) { red[wave * 32 + r] = s2; red[128 + wave * 32 + r] = q2; }
+        __syncthreads();
+        if (tid < 32) {
+            const double s4 = (double)red[tid] + (double)red[32 + tid] + (double)red[64 + tid] + (double)red[96 + tid];
+            const double q4 = (double)red[128 + tid] + (double)red[160 + tid] + (double)red[192 + tid] + (double)red[224 + tid];
+            atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s4);
+            atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 128-wide variant (P = 2)
 // For Cout % 128 == 0 (58 % of the UNet's FLOPs: the 128 -> 128 layers at full resolution).  512 threads = 8 waves: wave =
 // (z-slice zs, column group cg), the two column groups share ONE halo, so the GroupNorm-affine + plane-split staging is done once
@@ -768,7 +999,14 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
-    if (wide128) {
+    // x-strip variant for the column blocks the 64- and 128-wide kernels do not take (two-plane modes, one full-resolution source)
+    const int tiles8 = (int)gn_cdiv(D, 8) * p.tiles_y * p.tiles_x;
+    const bool strip = mode != GN_SPLIT_BF16X3 && !wide128 && !wide && C1 == 0 && (int64_t)tiles8 * (Cout / 32) * B >= 512;
+    if (strip) {
+        if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_strip_kernel<true>), dim3(tiles8 * (Cout / 32), B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_split_strip_kernel<false>), dim3(tiles8 * (Cout / 32), B), dim3(256), 0, st, p);
+        gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_strip_kernel<true>" : "conv3d_split_strip_kernel<false>");
+    } else if (wide128) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_wide_kernel<2, true>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_wide_kernel<2, false>), dim3(tiles * (Cout / 128), B), dim3(512), 0, st, p);
         gn_note_kernel(mode == GN_SPLIT_F16X2 ? "conv3d_split_wide_kernel<2, true>" : "conv3d_split_wide_kernel<2, false>");

@@ -610,7 +610,7 @@ def ggm3d_batch(vols, sigma):
 
 
 def minmax_batch(vols):
-    """-> (B,2) float32: (min, max) of every volume of a (B,...) batch; the per-volume size must be a multiple of 4"""
+    """-> (B,2) float32: (min, max) of every volume of a (B,...) batch"""
     _chk(vols, torch.float32, "vols")
     B = vols.shape[0]
     out = torch.empty((B, 2), dtype=torch.float32, device=vols.device)

@@ -39,6 +39,18 @@ def nan_placeholder(device):
 _FALLBACKS = {"count": 0}
 
 
+def _iso_capacity(model, Q, needed=None):
+    """per-model memory of how many vertices the iso-surfaces of this model's volumes have asked for (keyed by lattice size): the batched
+    MC33 launch sizes its output buffers from it (+25 %), so that a checkpoint whose surfaces are larger than the garment-like default
+    (6 Q^2 vertices) pays the one-volume-at-a-time redo once, not every batch.  needed: record a finished batch's demand"""
+    caps = model.__dict__.setdefault("_iso_caps", {})
+    if needed is not None:
+        if needed > caps.get(Q, 0):
+            caps[Q] = int(needed)
+        return None
+    return int(caps[Q] * 1.25) + 1024 if Q in caps else None
+
+
 def _warn_fallback():
     import warnings
     _FALLBACKS["count"] += 1
@@ -82,7 +94,7 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
         # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first)
         job = None
         if not auto_level:
-            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction)
+            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, cap_v=_iso_capacity(model, volume_size))
             job.enqueue(wnf_all)
         bad = torch.isnan(wnf_all).any()             # read after the batch's own host synchronisation
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
@@ -108,6 +120,8 @@ def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_di
         nocs_data = pointnet2_result["nocs_data"]
         B = nocs_data.num_graphs
         meshes = st["job"].finish() if st["job"] is not None else None
+        if st["job"] is not None:
+            _iso_capacity(model, st["job"].Q, st["job"].need_v)
         ptr = np.concatenate([[0], np.cumsum(nocs_data.sizes)])
         results = []
         if stop_on_nan and bool(bad):                # (after the batch's own synchronisation above: no extra stall on the common path)
@@ -209,7 +223,7 @@ class PredictJob:
             results, bad = _tail_phase(self.model, self.batch, self.state, level, sigma, direction, hole, False, split, self.arith)
             nan_seen = split and (results is None or bool(bad))
             if host and not nan_seen:
-                results = [to_host(r) for r in results]
+                results = to_host_batch(results)
                 self.state = None
                 return results
         cur = torch.cuda.current_stream(self.device)
@@ -218,7 +232,7 @@ class PredictJob:
         if nan_seen:                                # the fp32 re-run of THIS batch: its own arith value travels down its own calls
             _warn_fallback()
             results, _ = _predict_batch_once(self.model, self.batch, volume_size, level, sigma, direction, hole, False, False, self.arith.strict_fp32())
-            return [to_host(r) for r in results] if host else results
+            return to_host_batch(results) if host else results
         for r in results:                           # allocated on the tail stream, consumed on the caller's
             for v in r.values():
                 if torch.is_tensor(v) and v.is_cuda:
@@ -240,17 +254,44 @@ def predict_stream(model, batches, volume_size=128, iso_surface_level=0.5, gradi
         yield prev.finish()
 
 
+def _d2h(tensors):
+    """device tensors -> numpy arrays through pinned staging buffers (torch's caching host allocator: after the first batch the blocks
+    are recycled), all copies queued on the current stream, ONE synchronisation"""
+    out, dev = [], None
+    for t in tensors:
+        if not t.is_cuda:
+            out.append(t)
+            continue
+        dev = t.device
+        buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t, non_blocking=True)
+        out.append(buf)
+    if dev is not None:
+        torch.cuda.current_stream(dev).synchronize()
+    return [t.numpy() for t in out]
+
+
+def _mesh_items(res):
+    keys = ["verts", "faces", "normals", "volume_value", "volume_gradient_magnitude", "warp_field"]
+    keys += [k for k in ("is_on_surface", "is_on_surface_logits") if k in res]
+    dts = {"faces": torch.int32, "is_on_surface": torch.bool}
+    return keys, [res[k].detach().to(dts.get(k, torch.float32)) for k in keys]
+
+
 def to_host(res):
-    """numpy dict with the dtypes predict.py:191-199 writes."""
-    out = {
-        "verts": to_numpy(res["verts"]).astype(np.float32), "faces": to_numpy(res["faces"]).astype(np.int32),
-        "normals": to_numpy(res["normals"]).astype(np.float32), "volume_value": to_numpy(res["volume_value"]).astype(np.float32),
-        "volume_gradient_magnitude": to_numpy(res["volume_gradient_magnitude"]).astype(np.float32),
-        "warp_field": to_numpy(res["warp_field"]).astype(np.float32),
-    }
-    for k in ("is_on_surface", "is_on_surface_logits"):
-        if k in res:
-            out[k] = to_numpy(res[k])
+    """numpy dict with the dtypes predict.py:191-199 writes (conversions on the device, before the copy)."""
+    keys, tensors = _mesh_items(res)
+    return dict(zip(keys, _d2h(tensors)))
+
+
+def to_host_batch(results):
+    """[to_host(r) for r in results] with every copy of the batch queued before the ONE synchronisation"""
+    items = [_mesh_items(r) for r in results]
+    flat = _d2h([t for _, ts in items for t in ts])
+    out, i = [], 0
+    for keys, ts in items:
+        out.append(dict(zip(keys, flat[i:i + len(ts)])))
+        i += len(ts)
     return out
 
 

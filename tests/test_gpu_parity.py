@@ -265,8 +265,8 @@ def test_pipeline_ragged_batch_against_oracle():
 
 def test_batched_isosurface_tail_equals_per_garment():
     """wnf_batch_to_meshes_gpu (one set of launches and one host synchronisation for the batch) == wnf_to_mesh_gpu per garment, bit for
-    bit, including the error contract (level outside a volume's range -> ValueError entry); an odd lattice (Q^3 % 4 != 0) takes the
-    garment-by-garment route inside the same job"""
+    bit, including the error contract (level outside a volume's range -> ValueError entry); an odd lattice (Q^3 % 4 != 0: the volumes
+    of the batch start at addresses that are not 16-byte aligned) as well"""
     from garmentnets_amd.common import marching_cubes_util as MCU
     for Q in (24, 23):
         base = torch.from_numpy(S.shell_volume(Q)).float()
