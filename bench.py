@@ -243,8 +243,7 @@ class HbmMembers:
             out[name] = {"calls": g["calls"], "ms": g["ms"], "algorithmic_bytes": g["bytes"], "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
         if hasattr(ops, "mc33_batch_profiled") and wnf_all is not None:
             st = ops.mc33_batch_profiled(wnf_all, level)
-            B, Q = wnf_all.shape[0], wnf_all.shape[-1]
-            stages = {}
+            stages = {"mesh_vertices_per_batch": st.pop("_mesh")[1]}
             for k, (ms, byts) in st.items():
                 gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 stages[k] = {"ms": ms, "algorithmic_bytes": byts, "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
@@ -597,7 +596,8 @@ def main():
                 if auto_level[0]:
                     mm = torch.stack([wnf_all.min(), wnf_all.max()]).cpu()
                     lvl = 0.5 * (float(mm[0]) + float(mm[1]))
-                job = mcu.IsoBatchJob(args.volume_size, lvl, 0.5, "ascent")          # what predict_batch does after the lattice
+                from garmentnets_amd.predict import _iso_capacity
+                job = mcu.IsoBatchJob(args.volume_size, lvl, 0.5, "ascent", cap_v=_iso_capacity(model, args.volume_size))   # what predict_batch does after the lattice
                 job.enqueue(wnf_all)
                 meshes = job.finish()
                 q_all = job.padded_queries()

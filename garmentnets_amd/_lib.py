@@ -50,6 +50,7 @@ PROTOTYPES = {
     "gn_minmax_batch": [_vp, _i32, _i64, _vp, _vp],
     "gn_mc33_batch_workspace_bytes": [_i32, _i32, _i32, _i32],
     "gn_mc33_batch": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
+    "gn_mc33_batch_profiled": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
     "gn_mc33_workspace_bytes": [_i32, _i32, _i32],
     "gn_mc33": [_vp, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "gn_gather_nn": [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _vp, _vp],

@@ -7,12 +7,14 @@
 //              and the number of vertices this cell is the FIRST user of in sweep order (axis0 outer, axis2 inner):
 //              an edge is new for a cell iff no lexicographically earlier cell shares it, which depends only on the
 //              edge's position in the cell and on the cell touching the low boundary; the centre vertex is always new.
-//   scan     : exclusive prefix sums of (new vertices, triangles) over cells in sweep order
+//              One BYTE per cell (new vertices << 4 | triangles) + the packed sum of each 1024-cell block.
+//   scan     : exclusive prefix sums of (new vertices, triangles) over cells in sweep order: one small kernel over the block sums;
+//              the emit workgroups (one per block) rebuild their cells' prefixes from the count bytes -- no per-cell offsets in HBM
 //              => vertex ids = order of first use, faces in sweep order, exactly as the sequential algorithm.
-//   emit     : owners write vertex positions + the global edge->vertex table; every cell writes its faces;
-//              a per-vertex gather over the (<=4) adjacent cells, visited in sweep order, accumulates the normal
-//              contributions in the same order as the sequential algorithm and the max cell span ("values").
-// The look-up tables (13.4 KB, Lewiner et al. 2003) are staged into LDS by every workgroup.
+//   emit     : owners write vertex positions + the global edge->vertex table + the vertex's normal and value: a gather over the
+//              (<=4) adjacent cells, visited in sweep order, accumulates the normal contributions in the same order as the
+//              sequential algorithm and the max cell span ("values"); then every cell writes its faces.
+// The look-up tables (13.4 KB, Lewiner et al. 2003) are staged into LDS by the workgroups that hold a surface cell.
 #include "common.h"
 #include "mc33_luts.h"
 
@@ -66,6 +68,89 @@ __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restr
     out[t] = accum == 3 ? (float)__dsqrt_rn((double)v) : v;
 }
 
+// ---- fused form (radius <= GGM_R: sigma < 0.625, the reference's 0.5): the whole gradient magnitude of a GT x GT x 4 GT output tile in
+// ONE kernel -- input tile + halo staged in LDS with edge-replicated coordinates (so that every later pass is a plain correlation inside
+// the tile: replicate-at-each-pass composes), pass 0 along axis 0 with both kernels (derivative -> chain d = 0, Gaussian -> shared by
+// d = 1, 2), pass 1 along axis 1 (three chains), pass 2 along axis 2 squares and accumulates in the order d = 0, 1, 2 -- the arithmetic
+// of the 8-pass form (fp64 accumulation in scipy's order, fp32 rounding between the passes, correctly rounded sqrt), bit for bit, with
+// the compulsory HBM traffic only: each voxel read once (+ halo, mostly L2 hits) and written once instead of 8 round trips.
+#define GGM_R 2
+#define GGM_TZ 8
+#define GGM_TY 8
+#define GGM_TX 32
+__device__ __forceinline__ float ggm_corr(const float *c, int st, const GgmWeights &gw) {
+    const int r = gw.radius;
+    double acc;
+    if (gw.symmetric == 1) {
+        acc = __dmul_rn((double)c[0], gw.w[r]);
+        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)c[j * st], (double)c[-j * st]), gw.w[r + j]));
+    } else if (gw.symmetric == -1) {
+        acc = __dmul_rn((double)c[0], gw.w[r]);
+        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dsub_rn((double)c[j * st], (double)c[-j * st]), gw.w[r + j]));
+    } else {
+        acc = 0.0;
+        for (int j = -r; j <= r; ++j) acc = __dadd_rn(acc, __dmul_rn((double)c[j * st], gw.w[r + j]));
+    }
+    return (float)acc;
+}
+
+__global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1, int n2,
+                                                        GgmWeights w0, GgmWeights w1) {
+    constexpr int R = GGM_R, HZ = GGM_TZ + 2 * R, HY = GGM_TY + 2 * R, HX = GGM_TX + 2 * R;
+    constexpr int NA = HZ * HY * HX, NB1 = GGM_TZ * HY * HX, NC1 = GGM_TZ * GGM_TY * HX;
+    constexpr int REG0 = (3 * NC1 > NA) ? 3 * NC1 : NA;                    // the three pass-1 arrays overlay the (dead) input tile
+    __shared__ float lds[REG0 + 2 * NB1];
+    float *const A = lds, *const B = lds + REG0, *const C = lds;
+    const int64_t tot = (int64_t)n0 * n1 * n2;
+    in += (int64_t)blockIdx.y * tot;
+    out += (int64_t)blockIdx.y * tot;
+    const int tx_n = (n2 + GGM_TX - 1) / GGM_TX, ty_n = (n1 + GGM_TY - 1) / GGM_TY;
+    int t = blockIdx.x;
+    const int x0 = (t % tx_n) * GGM_TX; t /= tx_n;
+    const int y0 = (t % ty_n) * GGM_TY; t /= ty_n;
+    const int z0 = t * GGM_TZ;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NA; i += 256) {
+        const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+        int gz = z0 + hz - R, gy = y0 + hy - R, gx = x0 + hx - R;
+        gz = gz < 0 ? 0 : (gz >= n0 ? n0 - 1 : gz);
+        gy = gy < 0 ? 0 : (gy >= n1 ? n1 - 1 : gy);
+        gx = gx < 0 ? 0 : (gx >= n2 ? n2 - 1 : gx);
+        A[i] = in[((int64_t)gz * n1 + gy) * n2 + gx];
+    }
+    __syncthreads();
+    // pass 0 (axis 0): B[0] = corr(A, w1), B[1] = corr(A, w0) at z = 0 .. TZ-1, all (hy, hx)
+    for (int i = tid; i < NB1; i += 256) {
+        const int hx = i % HX, hy = (i / HX) % HY, z = i / (HX * HY);
+        const float *c = A + ((z + R) * HY + hy) * HX + hx;
+        B[i] = ggm_corr(c, HY * HX, w1);
+        B[NB1 + i] = ggm_corr(c, HY * HX, w0);
+    }
+    __syncthreads();
+    // pass 1 (axis 1): C[0] = corr(B[0], w0) (d = 0), C[1] = corr(B[1], w1) (d = 1), C[2] = corr(B[1], w0) (d = 2)
+    for (int i = tid; i < NC1; i += 256) {
+        const int hx = i % HX, y = (i / HX) % GGM_TY, z = i / (HX * GGM_TY);
+        const float *c = B + (z * HY + y + R) * HX + hx;
+        const float c0 = ggm_corr(c, HX, w0), c1 = ggm_corr(c + NB1, HX, w1), c2 = ggm_corr(c + NB1, HX, w0);
+        C[i] = c0;
+        C[NC1 + i] = c1;
+        C[2 * NC1 + i] = c2;
+    }
+    __syncthreads();
+    // pass 2 (axis 2): squares accumulated in the order d = 0, 1, 2 (fp32), correctly rounded square root
+    for (int i = tid; i < GGM_TZ * GGM_TY * GGM_TX; i += 256) {
+        const int x = i % GGM_TX, y = (i / GGM_TX) % GGM_TY, z = i / (GGM_TX * GGM_TY);
+        const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
+        if (gz >= n0 || gy >= n1 || gx >= n2) continue;
+        const float *c = C + (z * GGM_TY + y) * HX + x + R;
+        const float t0 = ggm_corr(c, 1, w0), t1 = ggm_corr(c + NC1, 1, w0), t2 = ggm_corr(c + 2 * NC1, 1, w1);
+        float v = __fmul_rn(t0, t0);
+        v = __fadd_rn(v, __fmul_rn(t1, t1));
+        v = __fadd_rn(v, __fmul_rn(t2, t2));
+        out[((int64_t)gz * n1 + gy) * n2 + gx] = (float)__dsqrt_rn((double)v);
+    }
+}
+
 static void ggm_kernel1d(double sigma, int order, int radius, GgmWeights &g) {
     // scipy _gaussian_kernel1d + the [::-1] of gaussian_filter1d
     const double sigma2 = sigma * sigma;
@@ -90,6 +175,7 @@ extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n
     GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
     const int radius = (int)(4.0 * sigma + 0.5);
     GN_REQUIRE(radius >= 1 && radius <= 32, "gn_ggm3d: unsupported sigma");
+    GN_REQUIRE(tmp != nullptr || radius <= GGM_R, "gn_ggm3d: tmp (2 volumes) is required for a kernel radius above %d", GGM_R);
     if (batch == 0) return GN_OK;
     GgmWeights w0, w1;
     ggm_kernel1d(sigma, 0, radius, w0);
@@ -97,6 +183,12 @@ extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n
     const int64_t tot = (int64_t)n0 * n1 * n2;
     float *t1 = tmp, *t2 = tmp + (int64_t)batch * tot;
     hipStream_t st = gn_stream(stream);
+    if (radius <= GGM_R) {                          // one fused launch (tmp is not touched)
+        const unsigned tiles = (unsigned)(gn_cdiv(n0, GGM_TZ) * gn_cdiv(n1, GGM_TY) * gn_cdiv(n2, GGM_TX));
+        hipLaunchKernelGGL(ggm_fused_kernel, dim3(tiles, (unsigned)batch), dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1);
+        GN_LAUNCH_CHECK("gn_ggm3d");
+        return GN_OK;
+    }
     dim3 grid((unsigned)gn_cdiv(tot, 256), (unsigned)batch), block(256);
     // scipy: for axis d, correlate along axes 0, 1, 2 in turn (derivative kernel on d, Gaussian on the others, fp32 between the passes),
     // square, accumulate in the order d = 0, 1, 2, square root.  The chains of d = 1 and d = 2 both start with the Gaussian along
@@ -397,47 +489,72 @@ __device__ __forceinline__ int64_t mc_edge_slot(const McDims &d, int x, int y, i
     return ((((int64_t)(z + dz) * d.n1 + (y + dy)) * d.n2 + (x + dx)) << 2) + j;
 }
 
+// One workgroup = one scan block of SCAN_ELEMS = 1024 cells in sweep order (4 per thread, strided by 256: coalesced).  Per cell it writes ONE
+// byte (new vertices << 4 | triangles; <= 13 and <= 12) and -- only for the cells the surface crosses, a few per cent -- the tiling row
+// (cinfo); the block's packed sum (nv << 32 | nt) goes straight to bsum, so the scan needs no pass of its own over the cells.
+#define SCAN_ELEMS 1024
 __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restrict__ vol, McDims d, double level,
-                                                          int32_t *__restrict__ cinfo, unsigned long long *__restrict__ counts) {
+                                                          int32_t *__restrict__ cinfo, unsigned char *__restrict__ cnt8,
+                                                          unsigned long long *__restrict__ bsum) {
     __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; counts += blockIdx.y * d.s_cnt;
-    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool inside = ci < d.ncells;
-    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
-    double v[8];
-    int index = 0;
-    if (inside) {
-        mc_load_cell(vol, d, x, y, z, level, v);
+    __shared__ unsigned long long wsum_c[4];
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; cnt8 += blockIdx.y * d.s_cnt; bsum += blockIdx.y * d.s_bsum;
+    const int64_t wg0 = (int64_t)blockIdx.x * SCAN_ELEMS;
+    double v[4][8];
+    int index[4];
+    bool any = false;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) index |= (v[i] > 0.0) ? (1 << i) : 0;
+    for (int k = 0; k < 4; ++k) {
+        const int64_t ci = wg0 + k * 256 + threadIdx.x;
+        index[k] = 0;
+        if (ci < d.ncells) {
+            const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+            mc_load_cell(vol, d, x, y, z, level, v[k]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) index[k] |= (v[k][i] > 0.0) ? (1 << i) : 0;
+        }
+        any |= index[k] != 0 && index[k] != 255;
     }
-    // the 13.4 KB of tables are staged only by workgroups that hold a cell the surface crosses (a few per cent of them: the staging,
-    // done by every workgroup, was most of this kernel's time)
-    if (!__syncthreads_or(index != 0 && index != 255)) {
-        if (inside) { cinfo[ci] = -1; counts[ci] = 0; }
+    // the 13.4 KB of tables are staged only by workgroups that hold a cell the surface crosses (a few per cent of them)
+    if (!__syncthreads_or(any)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t ci = wg0 + k * 256 + threadIdx.x;
+            if (ci < d.ncells) cnt8[ci] = 0;
+        }
+        if (threadIdx.x == 0) bsum[blockIdx.x] = 0;
         return;
     }
     mc_stage_lut(lut);
-    if (!inside) return;
-    int info = -1;
-    unsigned long long cnt = 0;
-    if (index != 0 && index != 255) {
-        int ntri = 0;
-        const int row = mc_resolve(lut, v, index, ntri);
-        if (row >= 0 && ntri > 0) {
-            unsigned used = 0;
-            for (int k = 0; k < ntri * 3; ++k) used |= 1u << lut[row + k];
-            const int nnew = __popc(used & mc_owned_mask(x, y, z));
-            info = row | (ntri << 16);
-            cnt = ((unsigned long long)nnew << 32) | (unsigned)ntri;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t ci = wg0 + k * 256 + threadIdx.x;
+        if (ci >= d.ncells) continue;
+        unsigned char c8 = 0;
+        if (index[k] != 0 && index[k] != 255) {
+            const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+            int ntri = 0, info = -1;
+            const int row = mc_resolve(lut, v[k], index[k], ntri);
+            if (row >= 0 && ntri > 0) {
+                unsigned used = 0;
+                for (int q = 0; q < ntri * 3; ++q) used |= 1u << lut[row + q];
+                const int nnew = __popc(used & mc_owned_mask(x, y, z));
+                info = row | (ntri << 16);
+                c8 = (unsigned char)((nnew << 4) | ntri);
+                mine += ((unsigned long long)nnew << 32) | (unsigned)ntri;
+            }
+            cinfo[ci] = info;                       // (cells the surface does not cross are never looked up: their entries stay unwritten)
         }
+        cnt8[ci] = c8;
     }
-    cinfo[ci] = info;
-    counts[ci] = cnt;
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0) wsum_c[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = wsum_c[0] + wsum_c[1] + wsum_c[2] + wsum_c[3];
 }
 
-// ---- exclusive scan of packed (nv<<32 | nt) counts, 1024 elements per block
-#define SCAN_ELEMS 1024
+// ---- exclusive scan of packed (nv<<32 | nt) counts, SCAN_ELEMS elements per block
 __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long *total) {
     __shared__ unsigned long long wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -533,31 +650,53 @@ __device__ __forceinline__ void mc_bit_order(const double *v, double *vv) {
     vv[0] = v[0]; vv[1] = v[1]; vv[2] = v[3]; vv[3] = v[2]; vv[4] = v[4]; vv[5] = v[5]; vv[6] = v[7]; vv[7] = v[6];
 }
 
-// surface cells are a few per cent of the cells: a workgroup scans MC_CELL_SLOTS cells per thread, queues the ones the surface crosses
-// in LDS and works them off with consecutive lanes (as mc_attrs_kernel does for the edge table)
-#define MC_CELL_SLOTS 8
-__device__ __forceinline__ unsigned mc_queue_cells(const int32_t *__restrict__ cinfo, const McDims &d, int64_t wg0, unsigned short *queue, unsigned *qn) {
+// A workgroup of the emit kernels = one scan block (SCAN_ELEMS cells): it rebuilds the exclusive prefix of its cells' packed counts from
+// the count bytes (4 consecutive cells per thread, block_excl_scan + the block's offset from scan_top_kernel) -- no per-cell offset
+// array in HBM -- and queues the cells the surface crosses (a few per cent) in LDS with their offsets, to be worked off by consecutive
+// lanes.  -> number of queued cells
+__device__ __forceinline__ unsigned mc_scan_queue(const unsigned char *__restrict__ cnt8, const unsigned long long *__restrict__ bsum, const McDims &d,
+                                                  int64_t wg0, unsigned short *queue, unsigned long long *qoff, unsigned *qn) {
     if (threadIdx.x == 0) *qn = 0;
-    __syncthreads();
+    const int64_t i0 = wg0 + threadIdx.x * 4;
+    unsigned c4 = 0;
+    if (i0 + 3 < d.ncells) c4 = *reinterpret_cast<const unsigned *>(cnt8 + i0);       // (i0 and the per-volume base are multiples of 4)
+    else
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < d.ncells) c4 |= (unsigned)cnt8[i0 + k] << (8 * k);
+    unsigned long long v[4], ssum = 0;
 #pragma unroll
-    for (int i = 0; i < MC_CELL_SLOTS; ++i) {
-        const int local = i * 256 + threadIdx.x;
-        const int64_t ci = wg0 + local;
-        if (ci < d.ncells && cinfo[ci] >= 0) queue[atomicAdd(qn, 1u)] = (unsigned short)local;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned c = (c4 >> (8 * k)) & 0xffu;
+        v[k] = ((unsigned long long)(c >> 4) << 32) | (c & 15u);
+        ssum += v[k];
+    }
+    unsigned long long tot;
+    unsigned long long ex = block_excl_scan(ssum, &tot) + bsum[blockIdx.x];          // (its barriers also publish *qn = 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (v[k] != 0) {
+            const unsigned slot = atomicAdd(qn, 1u);
+            queue[slot] = (unsigned short)(threadIdx.x * 4 + k);
+            qoff[slot] = ex;
+        }
+        ex += v[k];
     }
     __syncthreads();
     return *qn;
 }
 
 // owners: vertex ids, positions, edge table
+__device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
+                                            const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values);
+
 __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, const McDims &d, double level, const int8_t *lut, int64_t ci, int info,
-                                                const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
-                                                float *__restrict__ verts, int64_t cap_v) {
+                                                unsigned long long off, const int32_t *__restrict__ cinfo, int32_t *__restrict__ edge_vid,
+                                                float *__restrict__ verts, float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
     const int row = info & 0xffff, ntri = info >> 16;
     const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
     const unsigned owned = mc_owned_mask(x, y, z);
     unsigned seen = 0;
-    int64_t vid = (int64_t)(offs[ci] >> 32);
+    int64_t vid = (int64_t)(off >> 32);
     double v[8], vv[8];
     bool loaded = false;
     for (int k = 0; k < ntri * 3; ++k) {
@@ -594,43 +733,50 @@ __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, c
             py = __dadd_rn((double)y, __ddiv_rn(fy, ff));
             pz = __dadd_rn((double)z, __ddiv_rn(fz, ff));
         }
-        edge_vid[mc_edge_slot(d, x, y, z, e)] = (int32_t)vid;
+        const int64_t slot = mc_edge_slot(d, x, y, z, e);
+        edge_vid[slot] = (int32_t)vid;
         if (vid < cap_v) {
             verts[vid * 3 + 0] = (float)pz;  // array-axis order (axis0, axis1, axis2)
             verts[vid * 3 + 1] = (float)py;
             verts[vid * 3 + 2] = (float)px;
+            // normal / value of the new vertex: gather over the (<= 4) cells that share its edge, in sweep order (they are all crossed by
+            // the surface, so the classify pass has written their cinfo)
+            mc_attr_one(vol, d, level, cinfo, lut, slot, vid, normals, values);
         }
         ++vid;
     }
 }
 
 __global__ __launch_bounds__(256) void mc_vertices_kernel(const float *__restrict__ vol, McDims d, double level,
-                                                          const int32_t *__restrict__ cinfo,
-                                                          const unsigned long long *__restrict__ offs, int32_t *__restrict__ edge_vid,
-                                                          float *__restrict__ verts, int64_t cap_v) {
+                                                          const int32_t *__restrict__ cinfo, const unsigned char *__restrict__ cnt8,
+                                                          const unsigned long long *__restrict__ bsum, int32_t *__restrict__ edge_vid,
+                                                          float *__restrict__ verts, float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
     __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    __shared__ unsigned short queue[256 * MC_CELL_SLOTS];
+    __shared__ unsigned short queue[SCAN_ELEMS];
+    __shared__ unsigned long long qoff[SCAN_ELEMS];
     __shared__ unsigned qn;
-    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; offs += blockIdx.y * d.s_cnt; edge_vid += blockIdx.y * d.s_edge; verts += blockIdx.y * d.s_verts;
-    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_CELL_SLOTS);
-    const unsigned cnt = mc_queue_cells(cinfo, d, wg0, queue, &qn);
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; cnt8 += blockIdx.y * d.s_cnt; bsum += blockIdx.y * d.s_bsum;
+    edge_vid += blockIdx.y * d.s_edge; verts += blockIdx.y * d.s_verts; normals += blockIdx.y * d.s_verts; values += blockIdx.y * (d.s_verts / 3);
+    const int64_t wg0 = (int64_t)blockIdx.x * SCAN_ELEMS;
+    const unsigned cnt = mc_scan_queue(cnt8, bsum, d, wg0, queue, qoff, &qn);
     if (cnt == 0) return;                           // (workgroup-uniform) no surface cell here: no table staging
     mc_stage_lut(lut);
     for (unsigned k = threadIdx.x; k < cnt; k += 256) {
         const int64_t ci = wg0 + queue[k];
-        mc_vertices_one(vol, d, level, lut, ci, cinfo[ci], offs, edge_vid, verts, cap_v);
+        mc_vertices_one(vol, d, level, lut, ci, cinfo[ci], qoff[k], cinfo, edge_vid, verts, normals, values, cap_v);
     }
 }
 
-__global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *__restrict__ cinfo,
-                                                       const unsigned long long *__restrict__ offs,
+__global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *__restrict__ cinfo, const unsigned char *__restrict__ cnt8,
+                                                       const unsigned long long *__restrict__ bsum,
                                                        const int32_t *__restrict__ edge_vid, int32_t *__restrict__ faces, int64_t cap_f) {
     __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    __shared__ unsigned short queue[256 * MC_CELL_SLOTS];
+    __shared__ unsigned short queue[SCAN_ELEMS];
+    __shared__ unsigned long long qoff[SCAN_ELEMS];
     __shared__ unsigned qn;
-    cinfo += blockIdx.y * d.s_cinfo; offs += blockIdx.y * d.s_cnt; edge_vid += blockIdx.y * d.s_edge; faces += blockIdx.y * d.s_faces;
-    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_CELL_SLOTS);
-    const unsigned cnt = mc_queue_cells(cinfo, d, wg0, queue, &qn);
+    cinfo += blockIdx.y * d.s_cinfo; cnt8 += blockIdx.y * d.s_cnt; bsum += blockIdx.y * d.s_bsum; edge_vid += blockIdx.y * d.s_edge; faces += blockIdx.y * d.s_faces;
+    const int64_t wg0 = (int64_t)blockIdx.x * SCAN_ELEMS;
+    const unsigned cnt = mc_scan_queue(cnt8, bsum, d, wg0, queue, qoff, &qn);
     if (cnt == 0) return;
     mc_stage_lut(lut);
     for (unsigned q = threadIdx.x; q < cnt; q += 256) {
@@ -638,7 +784,7 @@ __global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *
         const int info = cinfo[ci];
         const int row = info & 0xffff, ntri = info >> 16;
         const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
-        const int64_t t0 = (int64_t)(offs[ci] & 0xffffffffull);
+        const int64_t t0 = (int64_t)(qoff[q] & 0xffffffffull);
         for (int k = 0; k < ntri * 3; ++k) {
             const int64_t f = t0 + k / 3;
             if (f < cap_f) faces[f * 3 + k % 3] = edge_vid[mc_edge_slot(d, x, y, z, lut[row + k])];
@@ -720,37 +866,6 @@ __device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const
     values[vid] = val;
 }
 
-// The edge table is almost empty (about 1 entry in 130 holds a vertex): a workgroup scans 16 entries per thread, queues the occupied
-// ones in LDS and then works them off with consecutive lanes -- one entry per thread left 63 of 64 lanes idle through the long fp64
-// body (the longest kernel of the iso stage), and 524 k workgroups per batch to launch.
-#define MC_ATTR_SLOTS 16
-__global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level,
-                                                       const int32_t *__restrict__ cinfo, const int32_t *__restrict__ edge_vid,
-                                                       float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
-    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
-    __shared__ unsigned short queue[256 * MC_ATTR_SLOTS];
-    __shared__ unsigned qn;
-    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; edge_vid += blockIdx.y * d.s_edge; normals += blockIdx.y * d.s_verts; values += blockIdx.y * (d.s_verts / 3);
-    const int64_t wg0 = (int64_t)blockIdx.x * (256 * MC_ATTR_SLOTS), n = d.nvox * 4;
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MC_ATTR_SLOTS; ++i) {
-        const int local = i * 256 + threadIdx.x;
-        const int64_t t = wg0 + local;
-        const int64_t vid = t < n ? edge_vid[t] : -1;
-        if (vid >= 0 && vid < cap_v) queue[atomicAdd(&qn, 1u)] = (unsigned short)local;   // (any order: every entry writes its own vertex)
-    }
-    __syncthreads();
-    const unsigned cnt = qn;
-    if (cnt == 0) return;                           // (workgroup-uniform) no vertex in these 1024 voxels: no table staging
-    mc_stage_lut(lut);
-    for (unsigned k = threadIdx.x; k < cnt; k += 256) {
-        const int64_t t = wg0 + queue[k];
-        mc_attr_one(vol, d, level, cinfo, lut, t, edge_vid[t], normals, values);
-    }
-}
-
 __global__ void mc_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts_dev, int64_t s_bsum) {
     total += blockIdx.x * s_bsum; counts_dev += 2 * blockIdx.x;
     counts_dev[0] = (int64_t)(*total >> 32);
@@ -762,7 +877,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t mc33_ws_one(int n0, int n1, int n2) {
     const size_t ncells = (size_t)(n0 - 1) * (n1 - 1) * (n2 - 1), nvox = (size_t)n0 * n1 * n2;
     const size_t nb = (ncells + SCAN_ELEMS - 1) / SCAN_ELEMS;
-    return align256(ncells * 4) + 2 * align256(ncells * 8) + align256(nvox * 16) + align256((nb + 1) * 8);
+    return align256(ncells * 4) + align256(ncells) + align256(nvox * 16) + align256((nb + 1) * 8);
 }
 
 extern "C" size_t gn_mc33_workspace_bytes(int n0, int n1, int n2) {
@@ -776,11 +891,15 @@ extern "C" size_t gn_mc33_batch_workspace_bytes(int batch, int n0, int n1, int n
 }
 
 // `batch` volumes of the same shape and level in one set of launches (blockIdx.y = volume): vol [batch][n0][n1][n2], verts / normals
-// [batch][cap_v][3], faces [batch][cap_f][3], values [batch][cap_v], counts_dev [batch][2].  The workspace is laid out array by array
-// ([batch] cell infos | [batch] counts | [batch] offsets | [batch] edge tables | [batch] block sums) so that one memset clears every
-// edge table.  Every volume's result is what gn_mc33 gives for it alone.
-extern "C" int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
-                             int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream) {
+// [batch][cap_v][3], faces [batch][cap_f][3], values [batch][cap_v], counts_dev [batch][2].  Workspace, array by array: [batch] tiling rows
+// (int32 per cell, written for the cells the surface crosses only) | [batch] count bytes | [batch] edge -> vertex tables (int32 x 4 per
+// voxel; written by the vertex owners, read by the faces of the cells that share the edge: never cleared, never scanned) | [batch] block
+// sums.  Five launches: classify (+ block sums) -> scan of the block sums -> counts -> vertices (+ normals / values) -> faces.
+// Every volume's result is what gn_mc33 gives for it alone.  stage_ms (host, 4 floats) != NULL: the call brackets its stages with HIP
+// events and SYNCHRONISES to fill (classify, scan + counts, vertices + attributes, faces) in milliseconds -- bench.py's hbm_members.
+static int mc33_batch_impl(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                           int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream,
+                           float *stage_ms) {
     GN_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "gn_mc33: input volume must be at least 2x2x2");
     GN_REQUIRE(batch >= 0 && batch <= 65535, "gn_mc33_batch: bad batch");
     if (batch == 0) return GN_OK;
@@ -792,34 +911,54 @@ extern "C" int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2
     d.nvox = (int64_t)n0 * n1 * n2;
     const int64_t nb = gn_cdiv(d.ncells, SCAN_ELEMS);
     d.s_cinfo = (int64_t)(align256(d.ncells * 4) / 4);
-    d.s_cnt = (int64_t)(align256(d.ncells * 8) / 8);
+    d.s_cnt = (int64_t)align256(d.ncells);
     d.s_edge = (int64_t)(align256(d.nvox * 16) / 4);
     d.s_bsum = (int64_t)(align256((nb + 1) * 8) / 8);
     d.s_verts = cap_v * 3;
     d.s_faces = cap_f * 3;
     char *p = (char *)ws;
     int32_t *cinfo = (int32_t *)p; p += (size_t)batch * d.s_cinfo * 4;
-    unsigned long long *counts = (unsigned long long *)p; p += (size_t)batch * d.s_cnt * 8;
-    unsigned long long *offs = (unsigned long long *)p; p += (size_t)batch * d.s_cnt * 8;
+    unsigned char *cnt8 = (unsigned char *)p; p += (size_t)batch * d.s_cnt;
     int32_t *edge_vid = (int32_t *)p; p += (size_t)batch * d.s_edge * 4;
     unsigned long long *bsum = (unsigned long long *)p;
     unsigned long long *total = bsum + nb;
     hipStream_t st = gn_stream(stream);
-    GN_HIP(hipMemsetAsync(edge_vid, 0xff, (size_t)batch * d.s_edge * 4, st), "gn_mc33(memset)");
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (stage_ms)
+        for (int i = 0; i < 5; ++i) GN_HIP(hipEventCreate(&ev[i]), "gn_mc33(event)");
+#define MC_MARK(i) do { if (stage_ms) GN_HIP(hipEventRecord(ev[i], st), "gn_mc33(event)"); } while (0)
     const unsigned nby = (unsigned)batch;
-    const dim3 blk(256), gcell((unsigned)gn_cdiv(d.ncells, 256), nby);
-    hipLaunchKernelGGL(mc_classify_kernel, gcell, blk, 0, st, vol, d, level, cinfo, counts);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb, nby), blk, 0, st, counts, d.ncells, bsum, d.s_cnt, d.s_bsum);
+    const dim3 blk(256), gblk((unsigned)nb, nby);
+    MC_MARK(0);
+    hipLaunchKernelGGL(mc_classify_kernel, gblk, blk, 0, st, vol, d, level, cinfo, cnt8, bsum);
+    MC_MARK(1);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1, nby), blk, 0, st, bsum, nb, total, d.s_bsum);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb, nby), blk, 0, st, counts, d.ncells, bsum, offs, d.s_cnt, d.s_bsum);
     hipLaunchKernelGGL(mc_counts_kernel, dim3(nby), dim3(1), 0, st, total, counts_dev, d.s_bsum);
-    const dim3 gcell8((unsigned)gn_cdiv(d.ncells, 256 * MC_CELL_SLOTS), nby);
-    hipLaunchKernelGGL(mc_vertices_kernel, gcell8, blk, 0, st, vol, d, level, cinfo, offs, edge_vid, verts, cap_v);
-    hipLaunchKernelGGL(mc_faces_kernel, gcell8, blk, 0, st, d, cinfo, offs, edge_vid, faces, cap_f);
-    hipLaunchKernelGGL(mc_attrs_kernel, dim3((unsigned)gn_cdiv(d.nvox * 4, 256 * MC_ATTR_SLOTS), nby), blk, 0, st, vol, d, level, cinfo, edge_vid, normals,
-                       values, cap_v);
+    MC_MARK(2);
+    hipLaunchKernelGGL(mc_vertices_kernel, gblk, blk, 0, st, vol, d, level, cinfo, cnt8, bsum, edge_vid, verts, normals, values, cap_v);
+    MC_MARK(3);
+    hipLaunchKernelGGL(mc_faces_kernel, gblk, blk, 0, st, d, cinfo, cnt8, bsum, edge_vid, faces, cap_f);
+    MC_MARK(4);
+#undef MC_MARK
     GN_LAUNCH_CHECK("gn_mc33");
+    if (stage_ms) {
+        GN_HIP(hipEventSynchronize(ev[4]), "gn_mc33(event)");
+        for (int i = 0; i < 4; ++i) GN_HIP(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]), "gn_mc33(event)");
+        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+    }
     return GN_OK;
+}
+
+extern "C" int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                             int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream) {
+    return mc33_batch_impl(vol, batch, n0, n1, n2, level, ws, ws_bytes, verts, faces, normals, values, cap_v, cap_f, counts_dev, stream, nullptr);
+}
+
+extern "C" int gn_mc33_batch_profiled(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                                      int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream,
+                                      float *stage_ms) {
+    GN_REQUIRE(stage_ms != nullptr, "gn_mc33_batch_profiled: stage_ms (host float[4]) is required");
+    return mc33_batch_impl(vol, batch, n0, n1, n2, level, ws, ws_bytes, verts, faces, normals, values, cap_v, cap_f, counts_dev, stream, stage_ms);
 }
 
 extern "C" int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,

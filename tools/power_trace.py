@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""10 Hz power / clock trace of a command (profiles/rNN_power*.csv): tools/power_trace.py <out.csv> <command...>
+
+Reads the amdgpu hwmon / sysfs nodes of every GPU card directly (power1_average | power1_input in uW, freq1_input = sclk in Hz,
+freq2_input = mclk, temp*_input, gpu_busy_percent) -- the rocm-smi CLI takes ~0.3 s per call, too slow for a 10 Hz trace; when no node is
+readable it falls back to one `rocm-smi --json` sample per period.  Columns: seconds since start, then per card power_w, sclk_mhz,
+mclk_mhz, busy_pct, temp_c.  The command's stdout / stderr pass through; exit code = the command's."""
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+
+def cards():
+    out = []
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+        if not hw or not os.path.exists(os.path.join(dev, "gpu_busy_percent")):
+            continue
+        out.append((os.path.basename(os.path.dirname(dev)), dev, hw[0]))
+    return out
+
+
+def rd(path, scale):
+    try:
+        return f"{float(open(path).read().split()[0]) * scale:.1f}"
+    except Exception:
+        return ""
+
+
+def sample_sysfs(cs):
+    row = []
+    for _, dev, hw in cs:
+        p = rd(os.path.join(hw, "power1_average"), 1e-6) or rd(os.path.join(hw, "power1_input"), 1e-6)
+        row += [p, rd(os.path.join(hw, "freq1_input"), 1e-6), rd(os.path.join(hw, "freq2_input"), 1e-6), rd(os.path.join(dev, "gpu_busy_percent"), 1.0),
+                rd(os.path.join(hw, "temp2_input"), 1e-3) or rd(os.path.join(hw, "temp1_input"), 1e-3)]
+    return row
+
+
+def sample_smi():
+    try:
+        d = json.loads(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showuse", "--showtemp", "--json"], capture_output=True, text=True, timeout=5).stdout)
+    except Exception:
+        return []
+    row = []
+    for card in sorted(d):
+        def num(pat):
+            for k, v in d[card].items():
+                if re.search(pat, k, re.I):
+                    m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
+                    if m:
+                        return m.group(0)
+            return ""
+        row += [num(r"power.*\(W\)"), num(r"sclk"), num(r"mclk"), num(r"GPU use"), num(r"Temperature.*(junction|hotspot|edge)")]
+    return row
+
+
+def main():
+    out, cmd = sys.argv[1], sys.argv[2:]
+    cs = cards()
+    use_sysfs = bool(cs) and any(v for v in sample_sysfs(cs))
+    names = [c[0] for c in cs] if use_sysfs else ["smi"]
+    stop = threading.Event()
+
+    def loop():
+        with open(out, "w") as f:
+            f.write("# source: " + ("amdgpu sysfs hwmon" if use_sysfs else "rocm-smi --json") + "\n")
+            f.write("t_s," + ",".join(f"{n}_{c}" for n in names for c in ("power_w", "sclk_mhz", "mclk_mhz", "busy_pct", "temp_c")) + "\n")
+            t0 = time.time()
+            while not stop.is_set():
+                row = sample_sysfs(cs) if use_sysfs else sample_smi()
+                f.write(f"{time.time() - t0:.2f}," + ",".join(row) + "\n")
+                f.flush()
+                stop.wait(0.1)
+    th = threading.Thread(target=loop, daemon=True)
+    th.start()
+    rc = subprocess.call(cmd)
+    stop.set()
+    th.join(timeout=5)
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    main()
