@@ -801,7 +801,8 @@ __device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const
     const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
     // local edge id seen from the adjacent cell at offset (-a,-b) in the two transverse axes, a = fast transverse axis
     //   x-edge: transverse (y,z): e(a,b) = {0,2,4,6}[a + 2b] ; y-edge: transverse (x,z): {3,1,7,5} ; z-edge: (x,y): {8,9,11,10}
-    const int EL[3][4] = {{0, 2, 4, 6}, {3, 1, 7, 5}, {8, 9, 11, 10}};
+    // (packed 4 bits per entry [j][a + 2b]: a table in memory is not needed)
+    const unsigned long long EL = 0xAB9857136420ull;
     float nx = 0.f, ny = 0.f, nz = 0.f, val = 0.f;
     const int ncell = (j == 3) ? 1 : 4;
     for (int q = 0; q < ncell; ++q) {
@@ -811,7 +812,7 @@ __device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const
             if (j == 0) { cy = y - a; cz = z - b; }
             else if (j == 1) { cx = x - a; cz = z - b; }
             else { cx = x - a; cy = y - b; }
-            e = EL[j][a + 2 * b];
+            e = (int)((EL >> (4 * (4 * j + a + 2 * b))) & 15ull);
         }
         if (cx < 0 || cy < 0 || cz < 0 || cx >= d.c2 || cy >= d.c1 || cz >= d.c0) continue;
         const int info = cinfo[((int64_t)cz * d.c1 + cy) * d.c2 + cx];

@@ -19,3 +19,22 @@ def degree(vb, rowp):
 for name, vb, rowp in (("P=2 per-voxel pad (old)", 80, 800), ("P=2 unpadded", 64, 640), ("P=2 row pad (new)", 64, 656),
                        ("P=3 per-voxel pad", 112, 1120), ("P=3 unpadded", 96, 960), ("P=3 row pad", 96, 976)):
     print(f"{name:26s} voxel {vb:3d} B row {rowp:4d} B: worst {degree(vb, rowp)[0]}-way, mean {degree(vb, rowp)[1]:.2f}")
+
+
+# ---- x-strip kernel (conv3d_split_strip_kernel): fragment row r -> halo row (zr = r >> 3, yr = r & 7) at ONE x; the 16 lanes of a service
+# group must hit 16 distinct 16-byte quads: row pitch RP and z pitch ZP in quads, mod 16
+def strip_degree(rpq, zpq):
+    worst = 0
+    for grp in GROUPS:
+        quads = {}
+        for r in grp:
+            q = ((r >> 3) * zpq + (r & 7) * rpq) % 16
+            quads[q] = quads.get(q, 0) + 1
+        worst = max(worst, max(quads.values()))
+    return worst
+
+
+print("x-strip halo, conflict-free (row pitch, z pitch) in quads mod 16:", [(a, b) for a in range(16) for b in range(16) if strip_degree(a, b) == 1])
+RP, ZP = 10 * 64 + 16, 10 * (10 * 64 + 16) + 224
+print(f"StripLayout: row pitch {RP} B = {RP // 16} quads (mod 16: {RP // 16 % 16}), z pitch {ZP} B = {ZP // 16} quads (mod 16: {ZP // 16 % 16}): "
+      f"{strip_degree(RP // 16 % 16, ZP // 16 % 16)}-way")
