@@ -686,8 +686,10 @@ __device__ __forceinline__ unsigned mc_scan_queue(const unsigned char *__restric
 }
 
 // owners: vertex ids, positions, edge table
-__device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
-                                            const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values);
+// (NOT inlined on purpose: inlined into the per-cell vertex loop below, hipcc 7.2 -O3 produced attributes of the wrong edge for some
+//  vertices -- caught by the bit-exact scikit-image goldens; as a real call the results are exact.  It runs for a few per cent of the cells.)
+__device__ __noinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
+                                         const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values);
 
 __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, const McDims &d, double level, const int8_t *lut, int64_t ci, int info,
                                                 unsigned long long off, const int32_t *__restrict__ cinfo, int32_t *__restrict__ edge_vid,
@@ -794,8 +796,8 @@ __global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *
 
 // per-vertex gather of normals / values over the adjacent cells in sweep order.  One thread per (voxel, slot).
 // one (voxel, slot) entry t that holds vertex vid
-__device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
-                                            const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
+__device__ __noinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
+                                         const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
     const int j = (int)(t & 3);
     const int64_t vx = t >> 2;
     const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
