@@ -11,9 +11,9 @@
 //   scan     : exclusive prefix sums of (new vertices, triangles) over cells in sweep order: one small kernel over the block sums;
 //              the emit workgroups (one per block) rebuild their cells' prefixes from the count bytes -- no per-cell offsets in HBM
 //              => vertex ids = order of first use, faces in sweep order, exactly as the sequential algorithm.
-//   emit     : owners write vertex positions + the global edge->vertex table + the vertex's normal and value: a gather over the
-//              (<=4) adjacent cells, visited in sweep order, accumulates the normal contributions in the same order as the
-//              sequential algorithm and the max cell span ("values"); then every cell writes its faces.
+//   emit     : owners write vertex positions + the global edge->vertex table; a dense pass over the VERTICES (one thread each) gathers
+//              the normal and value over the (<=4) cells adjacent to the vertex's edge, visited in sweep order: the normal contributions
+//              accumulate in the same order as the sequential algorithm, the value is the max cell span; then every cell writes its faces.
 // The look-up tables (13.4 KB, Lewiner et al. 2003) are staged into LDS by the workgroups that hold a surface cell.
 #include "common.h"
 #include "mc33_luts.h"
@@ -686,11 +686,6 @@ __device__ __forceinline__ unsigned mc_scan_queue(const unsigned char *__restric
 }
 
 // owners: vertex ids, positions, edge table
-// (NOT inlined on purpose: inlined into the per-cell vertex loop below, hipcc 7.2 -O3 produced attributes of the wrong edge for some
-//  vertices -- caught by the bit-exact scikit-image goldens; as a real call the results are exact.  It runs for a few per cent of the cells.)
-__device__ __noinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
-                                         const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values);
-
 __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, const McDims &d, double level, const int8_t *lut, int64_t ci, int info,
                                                 unsigned long long off, const int32_t *__restrict__ cinfo, int32_t *__restrict__ edge_vid,
                                                 float *__restrict__ verts, float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
@@ -741,9 +736,11 @@ __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, c
             verts[vid * 3 + 0] = (float)pz;  // array-axis order (axis0, axis1, axis2)
             verts[vid * 3 + 1] = (float)py;
             verts[vid * 3 + 2] = (float)px;
-            // normal / value of the new vertex: gather over the (<= 4) cells that share its edge, in sweep order (they are all crossed by
-            // the surface, so the classify pass has written their cinfo)
-            mc_attr_one(vol, d, level, cinfo, lut, slot, vid, normals, values);
+            // the vertex's edge slot is parked in its (not yet computed) normal row: mc_attrs_kernel, one thread per VERTEX, picks it up
+            // (a gather inlined here, inside the per-cell loop, was miscompiled by hipcc 7.2 -O3: wrong edge for some vertices, caught by
+            //  the bit-exact goldens; as its own dense pass over the vertices it is also perfectly balanced)
+            reinterpret_cast<unsigned *>(normals)[vid * 3 + 0] = (unsigned)((unsigned long long)slot & 0xffffffffull);
+            reinterpret_cast<unsigned *>(normals)[vid * 3 + 1] = (unsigned)((unsigned long long)slot >> 32);
         }
         ++vid;
     }
@@ -796,8 +793,8 @@ __global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *
 
 // per-vertex gather of normals / values over the adjacent cells in sweep order.  One thread per (voxel, slot).
 // one (voxel, slot) entry t that holds vertex vid
-__device__ __noinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
-                                         const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
+__device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const McDims &d, double level, const int32_t *__restrict__ cinfo,
+                                            const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
     const int j = (int)(t & 3);
     const int64_t vx = t >> 2;
     const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
@@ -869,6 +866,28 @@ __device__ __noinline__ void mc_attr_one(const float *__restrict__ vol, const Mc
     values[vid] = val;
 }
 
+// normals / values: one thread per vertex (4 per thread, strided), the vertex's edge slot read back from its normal row; the gather visits
+// the (<= 4) cells that share the edge in sweep order -- they are all crossed by the surface, so classify has written their tiling rows
+#define MC_ATTR_PER_WG 1024
+__global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level, const int32_t *__restrict__ cinfo,
+                                                       const int64_t *__restrict__ counts_dev, float *__restrict__ normals, float *__restrict__ values,
+                                                       int64_t cap_v) {
+    __shared__ __attribute__((aligned(16))) int8_t lut[MC_LUT_BYTES];
+    int64_t nv = counts_dev[2 * blockIdx.y];
+    if (nv > cap_v) nv = cap_v;
+    const int64_t v0 = (int64_t)blockIdx.x * MC_ATTR_PER_WG;
+    if (v0 >= nv) return;                           // (workgroup-uniform)
+    vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; normals += blockIdx.y * d.s_verts; values += blockIdx.y * (d.s_verts / 3);
+    mc_stage_lut(lut);
+    for (int k = 0; k < MC_ATTR_PER_WG / 256; ++k) {
+        const int64_t vid = v0 + k * 256 + threadIdx.x;
+        if (vid >= nv) break;
+        const unsigned *w = reinterpret_cast<const unsigned *>(normals) + vid * 3;
+        const int64_t t = (int64_t)((unsigned long long)w[0] | ((unsigned long long)w[1] << 32));
+        mc_attr_one(vol, d, level, cinfo, lut, t, vid, normals, values);
+    }
+}
+
 __global__ void mc_counts_kernel(const unsigned long long *__restrict__ total, int64_t *__restrict__ counts_dev, int64_t s_bsum) {
     total += blockIdx.x * s_bsum; counts_dev += 2 * blockIdx.x;
     counts_dev[0] = (int64_t)(*total >> 32);
@@ -897,7 +916,7 @@ extern "C" size_t gn_mc33_batch_workspace_bytes(int batch, int n0, int n1, int n
 // [batch][cap_v][3], faces [batch][cap_f][3], values [batch][cap_v], counts_dev [batch][2].  Workspace, array by array: [batch] tiling rows
 // (int32 per cell, written for the cells the surface crosses only) | [batch] count bytes | [batch] edge -> vertex tables (int32 x 4 per
 // voxel; written by the vertex owners, read by the faces of the cells that share the edge: never cleared, never scanned) | [batch] block
-// sums.  Five launches: classify (+ block sums) -> scan of the block sums -> counts -> vertices (+ normals / values) -> faces.
+// sums.  Six launches: classify (+ block sums) -> scan of the block sums -> counts -> vertices -> normals / values (one thread per vertex) -> faces.
 // Every volume's result is what gn_mc33 gives for it alone.  stage_ms (host, 4 floats) != NULL: the call brackets its stages with HIP
 // events and SYNCHRONISES to fill (classify, scan + counts, vertices + attributes, faces) in milliseconds -- bench.py's hbm_members.
 static int mc33_batch_impl(const float *vol, int batch, int n0, int n1, int n2, double level, void *ws, size_t ws_bytes, float *verts,
@@ -939,6 +958,8 @@ static int mc33_batch_impl(const float *vol, int batch, int n0, int n1, int n2, 
     hipLaunchKernelGGL(mc_counts_kernel, dim3(nby), dim3(1), 0, st, total, counts_dev, d.s_bsum);
     MC_MARK(2);
     hipLaunchKernelGGL(mc_vertices_kernel, gblk, blk, 0, st, vol, d, level, cinfo, cnt8, bsum, edge_vid, verts, normals, values, cap_v);
+    if (cap_v > 0)
+        hipLaunchKernelGGL(mc_attrs_kernel, dim3((unsigned)gn_cdiv(cap_v, MC_ATTR_PER_WG), nby), blk, 0, st, vol, d, level, cinfo, counts_dev, normals, values, cap_v);
     MC_MARK(3);
     hipLaunchKernelGGL(mc_faces_kernel, gblk, blk, 0, st, d, cinfo, cnt8, bsum, edge_vid, faces, cap_f);
     MC_MARK(4);

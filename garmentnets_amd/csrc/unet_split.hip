@@ -980,7 +980,11 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     p.tiles_x = (int)gn_cdiv(W, SP_TX);
     const int tiles = tz * p.tiles_y * p.tiles_x;
     const int Cin_total = C0 + C1;
-    const bool wide = (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024) && !tile_active;
+    const bool fits32 = (int64_t)D * H * W * C0 * 4 < ((int64_t)1 << 32);
+    // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work (its row loads address one sample of
+    // the full-resolution source with 32-bit byte offsets)
+    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && fits32 && (int64_t)tiles * (Cout / 128) * B >= 512;
+    const bool wide = !wide128 && (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
     // (MT = 2, the tall 8 x 8 x 8 tile, was measured on the 32-wide layers: 327-347 TFLOP/s vs 340 for MT = 1 -- its synchronous
     //  staging phase is 29 % of the kernel -- so it is not dispatched)
 #define SP_LAUNCH(P_, F16_)                                                                                                    \
@@ -989,13 +993,10 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
         else hipLaunchKernelGGL((conv3d_split_kernel<1, P_, F16_, 1>), dim3(tiles * (Cout / 32), B), dim3(256), 0, st, p);     \
         gn_note_kernel(wide ? "conv3d_split_kernel<2, " #P_ ", " #F16_ ", 1>" : "conv3d_split_kernel<1, " #P_ ", " #F16_ ", 1>"); \
     } while (0)
-    // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work
-    // an occupancy-aware launch pins the kernel variant (so that the border-class constants, taken from a launch over a tiny volume, come
-    // out of the same instruction stream): the 128-wide variant when Cout % 128 == 0, conv3d_split_kernel<1> otherwise
-    // (its row loads address one sample of the full-resolution source with 32-bit byte offsets)
-    const bool fits32 = (int64_t)D * H * W * C0 * 4 < ((int64_t)1 << 32);
-    const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && fits32 && ((int64_t)tiles * (Cout / 128) * B >= 512 || tile_active);
-    GN_REQUIRE(!tile_active || fits32, "gn_conv3d_gcr_split: the occupancy-aware launch needs D*H*W*C0*4 < 2^32 bytes per sample");
+    // The variant is chosen from the SHAPE alone -- an occupancy-aware launch (tile_active) takes the kernel the dense launch of the same
+    // shape takes, so the two give bit-identical outputs AND the same per-tile fp32 partials of the epilogue statistics.  (Outputs are
+    // bit-identical across all variants anyway: per element the products arrive in the same order; the border-class constants of an
+    // occupancy-aware layer may therefore come from a launch over a tiny volume, whichever variant that takes.)
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
