@@ -94,9 +94,36 @@ __device__ __forceinline__ float ggm_corr(const float *c, int st, const GgmWeigh
     return (float)acc;
 }
 
+// one correlation output from a register window win[0 .. 2R] (centre at R) -- same operation order as ggm_corr
+__device__ __forceinline__ float ggm_corr_win(const float *win, const GgmWeights &gw) {
+    constexpr int R = GGM_R;
+    const int r = gw.radius;
+    double acc;
+    if (gw.symmetric == 1) {
+        acc = __dmul_rn((double)win[R], gw.w[r]);
+#pragma unroll
+        for (int j = -R; j < 0; ++j)
+            if (j >= -r) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)win[R + j], (double)win[R - j]), gw.w[r + j]));
+    } else if (gw.symmetric == -1) {
+        acc = __dmul_rn((double)win[R], gw.w[r]);
+#pragma unroll
+        for (int j = -R; j < 0; ++j)
+            if (j >= -r) acc = __dadd_rn(acc, __dmul_rn(__dsub_rn((double)win[R + j], (double)win[R - j]), gw.w[r + j]));
+    } else {
+        acc = 0.0;
+#pragma unroll
+        for (int j = -R; j <= R; ++j)
+            if (j >= -r && j <= r) acc = __dadd_rn(acc, __dmul_rn((double)win[R + j], gw.w[r + j]));
+    }
+    return (float)acc;
+}
+
+// Every pass walks COLUMNS along its axis with the 2R+1 inputs of an output in a sliding register window: one LDS read per new input
+// instead of 2R+1 per output, and the (z, y, x) decomposition of an index once per column instead of once per output.
 __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1, int n2,
                                                         GgmWeights w0, GgmWeights w1) {
-    constexpr int R = GGM_R, HZ = GGM_TZ + 2 * R, HY = GGM_TY + 2 * R, HX = GGM_TX + 2 * R;
+    // HX: row pitch of the LDS tiles, ONE float of padding: pass 2 walks along x with lane = row, and 37 * row mod 32 is a permutation
+    constexpr int R = GGM_R, HZ = GGM_TZ + 2 * R, HY = GGM_TY + 2 * R, HXV = GGM_TX + 2 * R, HX = HXV + 1, WN = 2 * R + 1;
     constexpr int NA = HZ * HY * HX, NB1 = GGM_TZ * HY * HX, NC1 = GGM_TZ * GGM_TY * HX;
     constexpr int REG0 = (3 * NC1 > NA) ? 3 * NC1 : NA;                    // the three pass-1 arrays overlay the (dead) input tile
     __shared__ float lds[REG0 + 2 * NB1];
@@ -110,44 +137,86 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
     const int y0 = (t % ty_n) * GGM_TY; t /= ty_n;
     const int z0 = t * GGM_TZ;
     const int tid = threadIdx.x;
-    for (int i = tid; i < NA; i += 256) {
-        const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
-        int gz = z0 + hz - R, gy = y0 + hy - R, gx = x0 + hx - R;
+    // stage the tile + halo, edge-replicated: rows of HX consecutive x (one (hz, hy) decomposition per row)
+    for (int row = tid / 64; row < HZ * HY; row += 4) {
+        const int hy = row % HY, hz = row / HY;
+        int gz = z0 + hz - R, gy = y0 + hy - R;
         gz = gz < 0 ? 0 : (gz >= n0 ? n0 - 1 : gz);
         gy = gy < 0 ? 0 : (gy >= n1 ? n1 - 1 : gy);
-        gx = gx < 0 ? 0 : (gx >= n2 ? n2 - 1 : gx);
-        A[i] = in[((int64_t)gz * n1 + gy) * n2 + gx];
+        const float *src = in + ((int64_t)gz * n1 + gy) * n2;
+        const int hx = tid & 63;
+        if (hx < HXV) {
+            int gx = x0 + hx - R;
+            gx = gx < 0 ? 0 : (gx >= n2 ? n2 - 1 : gx);
+            A[row * HX + hx] = src[gx];
+        }
     }
     __syncthreads();
-    // pass 0 (axis 0): B[0] = corr(A, w1), B[1] = corr(A, w0) at z = 0 .. TZ-1, all (hy, hx)
-    for (int i = tid; i < NB1; i += 256) {
-        const int hx = i % HX, hy = (i / HX) % HY, z = i / (HX * HY);
-        const float *c = A + ((z + R) * HY + hy) * HX + hx;
-        B[i] = ggm_corr(c, HY * HX, w1);
-        B[NB1 + i] = ggm_corr(c, HY * HX, w0);
+    // pass 0 (axis 0): B[0] = corr(A, w1), B[1] = corr(A, w0) at z = 0 .. TZ-1; a thread owns (hy, hx) columns
+    for (int col = tid; col < HY * HX; col += 256) {
+        float win[WN];
+#pragma unroll
+        for (int j = 0; j < WN - 1; ++j) win[j + 1] = A[j * HY * HX + col];
+#pragma unroll
+        for (int z = 0; z < GGM_TZ; ++z) {
+#pragma unroll
+            for (int j = 0; j < WN - 1; ++j) win[j] = win[j + 1];
+            win[WN - 1] = A[(z + WN - 1) * HY * HX + col];
+            B[z * HY * HX + col] = ggm_corr_win(win, w1);
+            B[NB1 + z * HY * HX + col] = ggm_corr_win(win, w0);
+        }
     }
     __syncthreads();
-    // pass 1 (axis 1): C[0] = corr(B[0], w0) (d = 0), C[1] = corr(B[1], w1) (d = 1), C[2] = corr(B[1], w0) (d = 2)
-    for (int i = tid; i < NC1; i += 256) {
-        const int hx = i % HX, y = (i / HX) % GGM_TY, z = i / (HX * GGM_TY);
-        const float *c = B + (z * HY + y + R) * HX + hx;
-        const float c0 = ggm_corr(c, HX, w0), c1 = ggm_corr(c + NB1, HX, w1), c2 = ggm_corr(c + NB1, HX, w0);
-        C[i] = c0;
-        C[NC1 + i] = c1;
-        C[2 * NC1 + i] = c2;
+    // pass 1 (axis 1): C[0] = corr(B[0], w0) (d = 0), C[1] = corr(B[1], w1) (d = 1), C[2] = corr(B[1], w0) (d = 2); columns (z, hx)
+    for (int col = tid; col < GGM_TZ * HX; col += 256) {
+        const int hx = col % HX, z = col / HX;
+        const float *b0 = B + z * HY * HX + hx, *b1 = b0 + NB1;
+        float wa[WN], wb[WN];
+#pragma unroll
+        for (int j = 0; j < WN - 1; ++j) { wa[j + 1] = b0[j * HX]; wb[j + 1] = b1[j * HX]; }
+#pragma unroll
+        for (int y = 0; y < GGM_TY; ++y) {
+#pragma unroll
+            for (int j = 0; j < WN - 1; ++j) { wa[j] = wa[j + 1]; wb[j] = wb[j + 1]; }
+            wa[WN - 1] = b0[(y + WN - 1) * HX];
+            wb[WN - 1] = b1[(y + WN - 1) * HX];
+            const int o = (z * GGM_TY + y) * HX + hx;
+            const float c0 = ggm_corr_win(wa, w0), c1 = ggm_corr_win(wb, w1), c2 = ggm_corr_win(wb, w0);
+            C[o] = c0;
+            C[NC1 + o] = c1;
+            C[2 * NC1 + o] = c2;
+        }
     }
     __syncthreads();
-    // pass 2 (axis 2): squares accumulated in the order d = 0, 1, 2 (fp32), correctly rounded square root
+    // pass 2 (axis 2): squares accumulated in the order d = 0, 1, 2 (fp32), correctly rounded square root.  lane = one of the 64 (z, y) rows,
+    // wave = an 8-wide x chunk (conflict-free LDS reads thanks to the odd row pitch); the results go through LDS (the dead B region) so
+    // that the global stores are rows of 32 consecutive x
+    float *const O = B;
+    constexpr int OP = GGM_TX + 1;
+    {
+        constexpr int XC = GGM_TX / 4;
+        const int row = tid & 63, xs = (tid >> 6) * XC;
+        const float *c0 = C + row * HX + xs, *c1 = c0 + NC1, *c2 = c0 + 2 * NC1;
+        float w0v[WN], w1v[WN], w2v[WN];
+#pragma unroll
+        for (int j = 0; j < WN - 1; ++j) { w0v[j + 1] = c0[j]; w1v[j + 1] = c1[j]; w2v[j + 1] = c2[j]; }
+#pragma unroll
+        for (int x = 0; x < XC; ++x) {
+#pragma unroll
+            for (int j = 0; j < WN - 1; ++j) { w0v[j] = w0v[j + 1]; w1v[j] = w1v[j + 1]; w2v[j] = w2v[j + 1]; }
+            w0v[WN - 1] = c0[x + WN - 1]; w1v[WN - 1] = c1[x + WN - 1]; w2v[WN - 1] = c2[x + WN - 1];
+            const float t0 = ggm_corr_win(w0v, w0), t1 = ggm_corr_win(w1v, w0), t2 = ggm_corr_win(w2v, w1);
+            float v = __fmul_rn(t0, t0);
+            v = __fadd_rn(v, __fmul_rn(t1, t1));
+            v = __fadd_rn(v, __fmul_rn(t2, t2));
+            O[row * OP + xs + x] = (float)__dsqrt_rn((double)v);
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < GGM_TZ * GGM_TY * GGM_TX; i += 256) {
-        const int x = i % GGM_TX, y = (i / GGM_TX) % GGM_TY, z = i / (GGM_TX * GGM_TY);
+        const int x = i & (GGM_TX - 1), row = i / GGM_TX, y = row % GGM_TY, z = row / GGM_TY;
         const int gz = z0 + z, gy = y0 + y, gx = x0 + x;
-        if (gz >= n0 || gy >= n1 || gx >= n2) continue;
-        const float *c = C + (z * GGM_TY + y) * HX + x + R;
-        const float t0 = ggm_corr(c, 1, w0), t1 = ggm_corr(c + NC1, 1, w0), t2 = ggm_corr(c + 2 * NC1, 1, w1);
-        float v = __fmul_rn(t0, t0);
-        v = __fadd_rn(v, __fmul_rn(t1, t1));
-        v = __fadd_rn(v, __fmul_rn(t2, t2));
-        out[((int64_t)gz * n1 + gy) * n2 + gx] = (float)__dsqrt_rn((double)v);
+        if (gz < n0 && gy < n1 && gx < n2) out[((int64_t)gz * n1 + gy) * n2 + gx] = O[row * OP + x];
     }
 }
 

@@ -59,16 +59,32 @@ def sample_smi():
     return row
 
 
+def hip_card():
+    """sysfs card name of HIP device 0 (the node may show other tenants' GPUs too): PCI bus id from torch -> /sys/bus/pci/devices/*/drm/cardN"""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; p = torch.cuda.get_device_properties(0); "
+                            "print('%04x:%02x:%02x' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id))"], capture_output=True, text=True, timeout=300)
+        bdf = r.stdout.strip().splitlines()[-1]
+        for d in glob.glob(f"/sys/bus/pci/devices/{bdf}.*/drm/card[0-9]*"):
+            return os.path.basename(d)
+    except Exception:
+        pass
+    return None
+
+
 def main():
     out, cmd = sys.argv[1], sys.argv[2:]
+    mine = hip_card()
     cs = cards()
+    if mine is not None and any(c[0] == mine for c in cs):
+        cs = [c for c in cs if c[0] == mine]        # only the GPU this process can see
     use_sysfs = bool(cs) and any(v for v in sample_sysfs(cs))
     names = [c[0] for c in cs] if use_sysfs else ["smi"]
     stop = threading.Event()
 
     def loop():
         with open(out, "w") as f:
-            f.write("# source: " + ("amdgpu sysfs hwmon" if use_sysfs else "rocm-smi --json") + "\n")
+            f.write("# source: " + ("amdgpu sysfs hwmon" if use_sysfs else "rocm-smi --json") + f"; HIP device 0 = {mine}\n")
             f.write("t_s," + ",".join(f"{n}_{c}" for n in names for c in ("power_w", "sclk_mhz", "mclk_mhz", "busy_pct", "temp_c")) + "\n")
             t0 = time.time()
             while not stop.is_set():
