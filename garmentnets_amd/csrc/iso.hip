@@ -137,19 +137,26 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
     const int y0 = (t % ty_n) * GGM_TY; t /= ty_n;
     const int z0 = t * GGM_TZ;
     const int tid = threadIdx.x;
-    // stage the tile + halo, edge-replicated: rows of HX consecutive x (one (hz, hy) decomposition per row)
-    for (int row = tid / 64; row < HZ * HY; row += 4) {
-        const int hy = row % HY, hz = row / HY;
-        int gz = z0 + hz - R, gy = y0 + hy - R;
-        gz = gz < 0 ? 0 : (gz >= n0 ? n0 - 1 : gz);
-        gy = gy < 0 ? 0 : (gy >= n1 ? n1 - 1 : gy);
-        const float *src = in + ((int64_t)gz * n1 + gy) * n2;
-        const int hx = tid & 63;
-        if (hx < HXV) {
-            int gx = x0 + hx - R;
-            gx = gx < 0 ? 0 : (gx >= n2 ? n2 - 1 : gx);
-            A[row * HX + hx] = src[gx];
+    // stage the tile + halo, edge-replicated: rows of HXV consecutive x, a wave per row; ALL of a thread's loads are issued before the first
+    // LDS store (36 dependent load -> store round trips per thread were most of this kernel's time)
+    {
+        constexpr int NROW = HZ * HY / 4;            // rows per wave
+        static_assert(HZ * HY % 4 == 0, "rows split evenly over the 4 waves");
+        const int hx = tid & 63, w = tid >> 6;
+        int gx = x0 + hx - R;
+        gx = gx < 0 ? 0 : (gx >= n2 ? n2 - 1 : gx);
+        float tmp[NROW];
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+            const int row = w + 4 * i, hy = row % HY, hz = row / HY;
+            int gz = z0 + hz - R, gy = y0 + hy - R;
+            gz = gz < 0 ? 0 : (gz >= n0 ? n0 - 1 : gz);
+            gy = gy < 0 ? 0 : (gy >= n1 ? n1 - 1 : gy);
+            tmp[i] = hx < HXV ? in[((int64_t)gz * n1 + gy) * n2 + gx] : 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < NROW; ++i)
+            if (hx < HXV) A[(w + 4 * i) * HX + hx] = tmp[i];
     }
     __syncthreads();
     // pass 0 (axis 0): B[0] = corr(A, w1), B[1] = corr(A, w0) at z = 0 .. TZ-1; a thread owns (hy, hx) columns
