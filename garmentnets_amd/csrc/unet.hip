@@ -299,9 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
     // ---- epilogue: ReLU, coalesced stores, optional statistics of the output
     const int gz = z0 + wave;
     const bool full = z0 + CV_TZ <= p.D && y0 + CV_TY <= p.H && x0 + CV_TX <= p.W;    // tile inside the volume (workgroup-uniform)
-    float ssum[NT], ssq[NT];
+    double ssum[NT], ssq[NT];                       // fp64 per lane: the statistics do not depend on the kernel variant (see unet_split.hip)
 #pragma unroll
-    for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+    for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
                     float v = tot[t][u][q];
                     if (p.relu) v = gn_relu(v);
                     ob[(q >> 2) * rs + (int64_t)(q & 3) * p.Cout] = v;
-                    ssum[u] += v;
-                    ssq[u] = fmaf(v, v, ssq[u]);
+                    ssum[u] += (double)v;
+                    ssq[u] += (double)v * (double)v;
                 }
                 continue;
             }
@@ -329,22 +329,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_gcr_kernel(ConvArgs p) {
                     float v = tot[t][u][q];
                     if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
-                    ssum[u] += v;
-                    ssq[u] = fmaf(v, v, ssq[u]);
+                    ssum[u] += (double)v;
+                    ssq[u] += (double)v * (double)v;
                 }
             }
         }
     if (p.osum) {
-        float *red = halo;   // [2][4 waves][CT]; every wave is past its last halo / weight read (barrier after the last tap)
+        double *red = reinterpret_cast<double *>(halo);   // [2][4 waves][CT]; every wave is past its last halo / weight read (barrier after the last tap)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            const float s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
+            const double s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
             if (h == 0) { red[wave * CT + u * 32 + r] = s2; red[4 * CT + wave * CT + u * 32 + r] = q2; }
         }
         __syncthreads();
         if (tid < CT) {
-            const double s4 = (double)red[tid] + (double)red[CT + tid] + (double)red[2 * CT + tid] + (double)red[3 * CT + tid];
-            const double q4 = (double)red[4 * CT + tid] + (double)red[5 * CT + tid] + (double)red[6 * CT + tid] + (double)red[7 * CT + tid];
+            const double s4 = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
+            const double q4 = red[4 * CT + tid] + red[5 * CT + tid] + red[6 * CT + tid] + red[7 * CT + tid];
             atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s4);
             atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
         }

@@ -111,7 +111,7 @@ __device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const 
 // workgroup-uniform element offset from there (the generic path below spent ~40 instructions per value, five of them quarter-rate
 // integer multiplies, on 64-bit addresses and bounds: 9 % of the 128 -> 128 layer, 25 % of a 32 -> 32 one).  Same arithmetic, same
 // order as the generic path: value * scale (+ polyphase partial) (ReLU), channel statistics accumulated q = 0 .. 15.
-__device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32x16s &val, float osc, float *ob, const float *pb, float &ssum, float &ssq) {
+__device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32x16s &val, float osc, float *ob, const float *pb, double &ssum, double &ssq) {
     const int64_t rs = (int64_t)p.W * p.Cout;
     float pv[16];
     if (pb) {
@@ -129,8 +129,8 @@ __device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32
         if (pb) v = __fadd_rn(v, pv[q]);
         if (p.relu) v = gn_relu(v);
         ob[j * rs + (int64_t)k * p.Cout] = v;
-        ssum += v;
-        ssq = fmaf(v, v, ssq);
+        ssum += (double)v;
+        ssq += (double)v * (double)v;
     }
 }
 
@@ -388,9 +388,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     }
     __syncthreads();                                // the epilogue reuses the halo as scratch
     // ---- epilogue (identical to the fp32 kernel)
-    float ssum[NT], ssq[NT];
+    // channel statistics in fp64 per lane: sums of fp32 values are then exact to ~1e-16, so the GroupNorm statistics a layer hands on do not
+    // depend on which kernel variant (tile shape, fragment-to-lane mapping) produced them -- a garment's result is the same in any batch
+    double ssum[NT], ssq[NT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+    for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
     const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -422,22 +424,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
-                    ssum[u] += v;
-                    ssq[u] = fmaf(v, v, ssq[u]);
+                    ssum[u] += (double)v;
+                    ssq[u] += (double)v * (double)v;
                 }
             }
         }
     if (p.osum) {
-        float *red = reinterpret_cast<float *>(halo);
+        double *red = reinterpret_cast<double *>(halo);
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            const float s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
+            const double s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
             if (h == 0) { red[wave * CT + u * 32 + r] = s2; red[4 * CT + wave * CT + u * 32 + r] = q2; }
         }
         __syncthreads();
         if (tid < CT) {
-            const double s4 = (double)red[tid] + (double)red[CT + tid] + (double)red[2 * CT + tid] + (double)red[3 * CT + tid];
-            const double q4 = (double)red[4 * CT + tid] + (double)red[5 * CT + tid] + (double)red[6 * CT + tid] + (double)red[7 * CT + tid];
+            const double s4 = red[tid] + red[CT + tid] + red[2 * CT + tid] + red[3 * CT + tid];
+            const double q4 = red[4 * CT + tid] + red[5 * CT + tid] + red[6 * CT + tid] + red[7 * CT + tid];
             atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s4);
             atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
         }
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
     }
     __syncthreads();                                // the epilogue reuses the halo as scratch
     // ---- epilogue: fragment xo of this wave = rows (zr = q >> 2, yr = (q & 3) + 4 h) at x = x0 + xw + xo, lane r = channel
-    float ssum = 0.f, ssq = 0.f;
+    double ssum = 0.0, ssq = 0.0;                   // fp64 per lane (see conv3d_split_kernel)
     const int n = n0 + r;
     const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
     const bool full = !inactive && z0 + T <= p.D && y0 + T <= p.H && x0 + T <= p.W;       // (workgroup-uniform)
@@ -634,8 +636,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
                 if (p.partial) v = __fadd_rn(v, pv[q]);
                 if (p.relu) v = gn_relu(v);
                 ob[(q >> 2) * zs_ + (q & 3) * rs] = v;
-                ssum += v;
-                ssq = fmaf(v, v, ssq);
+                ssum += (double)v;
+                ssq += (double)v * (double)v;
             }
         }
     } else {
@@ -656,19 +658,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
-                    ssum += v;
-                    ssq = fmaf(v, v, ssq);
+                    ssum += (double)v;
+                    ssq += (double)v * (double)v;
                 }
             }
     }
     if (p.osum) {
-        float *red = reinterpret_cast<float *>(halo);
-        const float s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
+        double *red = reinterpret_cast<double *>(halo);
+        const double s2 = ssum + __shfl_xor(ssum, 32), q2 = ssq + __shfl_xor(ssq, 32);
         if (h == 0) { red[wave * 32 + r] = s2; red[128 + wave * 32 + r] = q2; }
         __syncthreads();
         if (tid < 32) {
-            const double s4 = (double)red[tid] + (double)red[32 + tid] + (double)red[64 + tid] + (double)red[96 + tid];
-            const double q4 = (double)red[128 + tid] + (double)red[160 + tid] + (double)red[192 + tid] + (double)red[224 + tid];
+            const double s4 = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+            const double q4 = red[128 + tid] + red[160 + tid] + red[192 + tid] + red[224 + tid];
             atomicAdd(&p.osum[(int64_t)b * p.Cout + n0 + tid], s4);
             atomicAdd(&p.osq[(int64_t)b * p.Cout + n0 + tid], q4);
         }
@@ -897,9 +899,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     }
     __syncthreads();                                // pad-step DMAs landed; the epilogue reuses the halo as scratch
     const int gz = z0 + zl;
-    float ssum[NT], ssq[NT];
+    // channel statistics in fp64 per lane: sums of fp32 values are then exact to ~1e-16, so the GroupNorm statistics a layer hands on do not
+    // depend on which kernel variant (tile shape, fragment-to-lane mapping) produced them -- a garment's result is the same in any batch
+    double ssum[NT], ssq[NT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) { ssum[u] = 0.f; ssq[u] = 0.f; }
+    for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
     const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -930,24 +934,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                         if (p.relu) v = gn_relu(v);
                     }
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
-                    ssum[u] += v;
-                    ssq[u] = fmaf(v, v, ssq[u]);
+                    ssum[u] += (double)v;
+                    ssq[u] += (double)v * (double)v;
                 }
             }
         }
     if (p.osum) {
-        float *red = reinterpret_cast<float *>(smem);                           // [sum | sq][cg][zs][64]
+        double *red = reinterpret_cast<double *>(smem);                         // [sum | sq][cg][zs][64]
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            const float s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
+            const double s2 = ssum[u] + __shfl_xor(ssum[u], 32), q2 = ssq[u] + __shfl_xor(ssq[u], 32);
             if (h == 0) { red[(cg * 4 + zs) * 64 + u * 32 + r] = s2; red[512 + (cg * 4 + zs) * 64 + u * 32 + r] = q2; }
         }
         __syncthreads();
         if (tid < 128) {
             const int g = tid >> 6, c = tid & 63;
-            const float *rs = red + g * 256 + c, *rq = red + 512 + g * 256 + c;
-            const double s4 = (double)rs[0] + (double)rs[64] + (double)rs[128] + (double)rs[192];
-            const double q4 = (double)rq[0] + (double)rq[64] + (double)rq[128] + (double)rq[192];
+            const double *rs = red + g * 256 + c, *rq = red + 512 + g * 256 + c;
+            const double s4 = rs[0] + rs[64] + rs[128] + rs[192];
+            const double q4 = rq[0] + rq[64] + rq[128] + rq[192];
             atomicAdd(&p.osum[(int64_t)b * p.Cout + cb * 128 + tid], s4);
             atomicAdd(&p.osq[(int64_t)b * p.Cout + cb * 128 + tid], q4);
         }
