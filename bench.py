@@ -278,9 +278,9 @@ def measured_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs
     of THIS command, corrected as profiles/*_fetch_calibration.txt documents; tools/pmc_summary.py) -- only quoted when the workload is
     the one that was profiled.  -> (bytes or None, source file or None)"""
-    if (args.workload, args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode) != ("full", 16, 6000, 128, "mean", 128, "f16x2"):
+    if (args.workload, args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode, args.input) != ("full", 16, 6000, 128, "mean", 128, "f16x2", "planted"):
         return None, None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json",):
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             k = json.load(open(path))["kernels"].get(kernel)
