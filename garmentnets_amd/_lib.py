@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gn_mesh_compact": [_vp, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp],
     "gn_scale_verts": [_vp, _i64, _f64, _vp, _vp],
     "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_implicit_decode_lattice_split": [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }

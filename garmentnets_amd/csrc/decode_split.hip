@@ -49,7 +49,62 @@ struct DecSplitArgs {
     const float *xscale;             // NULL or device {s_x, 1 / s_x, unsafe, 0}: the garment's input scale (exact power of two); unsafe != 0:
                                      // this kernel does nothing (the caller's gated fp32 kernel computes the rows instead)
     float *out; int ldo;
+    // lattice form (LAT): the rows are not read from xin but sampled here -- lattice point m0 + m of the (Q,Q,Q) grid of predict.py:145-147 from
+    // the channel-last volume vol [D][H][W][32] (trilinear, border, align_corners: the arithmetic of decode.hip, bit for bit)
+    const float *vol; int D, H, W, Q; long long m0;
 };
+
+// ---- lattice sampling (LAT).  A lane owns 16 channels of its query: 8h..8h+7 and 16+8h..16+8h+7 = four float4 per corner.
+struct LatQuery {
+    unsigned goff;                   // byte offset of corner (x0, y0, z0), channel 8h, inside the volume (< 2^32: checked on the host)
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    unsigned ok1;                    // bit 0 / 1 / 2: x0+1 / y0+1 / z0+1 inside the volume (the lower corners always are, after the border clamp)
+};
+
+__device__ __forceinline__ float lat_src_index(float q, int size) {        // = src_index of decode.hip
+    const float qn = __fsub_rn(__fmul_rn(2.0f, q), 1.0f);
+    const float x = __fmul_rn(__fdiv_rn(__fadd_rn(qn, 1.0f), 2.0f), (float)(size - 1));
+    return fminf((float)(size - 1), fmaxf(x, 0.0f));
+}
+
+__device__ __forceinline__ LatQuery lat_setup(const DecSplitArgs &p, long long m, int h) {
+    const unsigned g = (unsigned)(p.m0 + m), uq = (unsigned)p.Q;          // Q^3 < 2^32 (checked on the host): 32-bit divides
+    const unsigned gq = g / uq;
+    const int k = (int)(g - gq * uq), i = (int)(gq / uq), j = (int)(gq - (unsigned)i * uq);
+    const float sc = __fdiv_rn(1.0f, __fsub_rn((float)p.Q, 1.0f));
+    const float qx = __fadd_rn(__fmul_rn((float)i, sc), -0.0f), qy = __fadd_rn(__fmul_rn((float)j, sc), -0.0f), qz = __fadd_rn(__fmul_rn((float)k, sc), -0.0f);
+    const float ix = lat_src_index(qx, p.W), iy = lat_src_index(qy, p.H), iz = lat_src_index(qz, p.D);     // component 0 indexes the LAST volume axis
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
+    LatQuery q;
+    q.wx1 = __fsub_rn(ix, fx0); q.wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+    q.wy1 = __fsub_rn(iy, fy0); q.wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+    q.wz1 = __fsub_rn(iz, fz0); q.wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+    q.ok1 = (x0 + 1 < p.W ? 1u : 0u) | (y0 + 1 < p.H ? 2u : 0u) | (z0 + 1 < p.D ? 4u : 0u);
+    q.goff = ((unsigned)((z0 * p.H + y0) * p.W + x0) * 32u + 8u * (unsigned)h) * 4u;
+    return q;
+}
+__device__ __forceinline__ bool lat_ok(const LatQuery &q, int c) { return ((c & 1) == 0 || (q.ok1 & 1u)) && ((c & 2) == 0 || (q.ok1 & 2u)) && ((c & 4) == 0 || (q.ok1 & 4u)); }
+__device__ __forceinline__ float lat_weight(const LatQuery &q, int c) {
+    return __fmul_rn(__fmul_rn((c & 1) ? q.wx1 : q.wx0, (c & 2) ? q.wy1 : q.wy0), (c & 4) ? q.wz1 : q.wz0);
+}
+// byte offset of corner c (a corner outside the volume reads corner 0: its value is never used)
+__device__ __forceinline__ unsigned lat_corner(const DecSplitArgs &p, const LatQuery &q, int c) {
+    return lat_ok(q, c) ? q.goff + (unsigned)((((c >> 2) * p.H + ((c >> 1) & 1)) * p.W + (c & 1)) * 128) : q.goff;
+}
+typedef float lat_f4 __attribute__((ext_vector_type(4)));
+// the four float4 of one corner, issued from inline asm (scalar base + 32-bit offset): invisible to hipcc's vmcnt bookkeeping, which would
+// otherwise drain the weight-DMA ring at every use; the caller waits by hand (counted s_waitcnt) and pins the first use behind that wait
+// half a corner (2 float4 = 8 of the lane's 16 channels; half 0: channels 8h.., half 1: 16 + 8h..)
+__device__ __forceinline__ void lat_issue(const float *vol, unsigned off, int half, lat_f4 (&t)[2]) {
+    if (half == 0) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t[0]) : "v"(off), "s"(vol) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(t[1]) : "v"(off), "s"(vol) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(t[0]) : "v"(off), "s"(vol) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:80" : "=v"(t[1]) : "v"(off), "s"(vol) : "memory");
+    }
+}
 
 __device__ __forceinline__ void ds_split2(float a, float b, unsigned &p1, unsigned &p2) {
     const f32x2q v = {a, b};
@@ -86,8 +141,9 @@ __device__ __forceinline__ void ds_glds16_s(const void *sbase, unsigned voff, un
 // registers no longer fit without ~40 spilled values since the NaN-propagating ReLU, 0.34 ms per 262144 rows), 2 when the UNet's final 1x1x1
 // convolution (32 -> 128, linear) has been folded into the first layer on the host (pack_decode_split(..., final_conv)): the
 // decoder then reads 32-channel rows sampled from the PRE-final feature volume.
-template <int OUTC, int K0G>
+template <int OUTC, int K0G, bool LAT = false>
 __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit_decode_split_kernel(DecSplitArgs p) {
+    static_assert(!LAT || (K0G == 2 && OUTC == 1), "the lattice form exists for the folded scalar decoder");
     // K0G = 2: the first-layer planes are 16 registers instead of 64, which leaves room for TWO workgroups per CU (2 waves per SIMD:
     // one wave's epilogue / load work overlaps the other's MFMAs by itself) with a single accumulator set and an immediate epilogue
     // (scalar output only: the 2-4 output variants need the registers of the second wave for their w3 tables)
@@ -97,8 +153,14 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     constexpr int NRAW = 2 * K0G;                                          // float4 row loads per lane per tile
     constexpr int RAW_STAGE = NSTAGE - 8;                                  // where the next tile's rows are requested
     static_assert(NSTEPS % 4 == 0 && (K0G == 2 || K0G == 8), "stage = 4 k-group steps");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[DS_RING * DS_STAGE_BYTES + ((TABN * 4 + 15) / 16) * 16];
-    float *const tab = reinterpret_cast<float *>(smem + DS_RING * DS_STAGE_BYTES);
+    // LAT: a 3-stage ring (two stages ahead) makes room in LDS for the gather's accumulators [4][256] float4 and its per-lane query record
+    // [8][256] dwords: the kernel has no REGISTERS to spare for them (239 of 256 without the gather)
+    constexpr int RING = LAT ? 3 : DS_RING;
+    constexpr int TAB_BYTES = ((TABN * 4 + 15) / 16) * 16, LATB = LAT ? (16 + 8) * 1024 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * DS_STAGE_BYTES + TAB_BYTES + LATB];
+    float *const tab = reinterpret_cast<float *>(smem + RING * DS_STAGE_BYTES);
+    float4 *const lacc = reinterpret_cast<float4 *>(smem + RING * DS_STAGE_BYTES + TAB_BYTES);           // [4][256]: conflict-free b128
+    unsigned *const lrec = reinterpret_cast<unsigned *>(smem + RING * DS_STAGE_BYTES + TAB_BYTES + 16 * 1024);   // [8][256]
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,21 +178,43 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     const unsigned char *wsrc = p.wp + (wave * 4) * 1024;   // wave-uniform (SGPRs); the lane adds 16 * lane
     const unsigned lane16 = lane * 16;
     int sb = 0;                                     // stays 0 (and folds away) when NSTAGE % 4 == 0
-    constexpr bool SB_ZERO = (NSTAGE % 4 == 0);
+    constexpr bool SB_ZERO = (NSTAGE % RING == 0);
+    static_assert(!LAT || SB_ZERO, "the 3-stage ring is indexed with compile-time slots");
 #define DS_SB (SB_ZERO ? 0 : sb)
 #define DS_ISSUE(STAGE, SLOT)                                                                                                  \
     _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
         ds_glds16_s(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lane16, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
-    DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2) DS_ISSUE(3, 3)
+    DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2)
+    if (!LAT) { DS_ISSUE(3, 3) }
 
     // first tile's rows: lane (h, r) holds the 8 channels 16g + 8h .. + 7 of query r for g = 0..K0G-1
     float4 raw[NRAW];
     {
         long long m = (long long)blockIdx.x * DS_TILE + wave * 32 + r;
         if (m >= p.M) m = p.M - 1;
-        const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+        if constexpr (LAT) {                        // first tile: sampled synchronously (plain loads; the prologue is drained below anyway)
+            const LatQuery lq = lat_setup(p, m, h);
 #pragma unroll
-        for (int g = 0; g < K0G; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
+            for (int g = 0; g < NRAW; ++g) raw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (lat_ok(lq, c)) {
+                    const float4 *cp = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(p.vol) + lat_corner(p, lq, c));
+                    const float w = lat_weight(lq, c);
+                    const float4 v[4] = {cp[0], cp[1], cp[4], cp[5]};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        raw[g].x = __fadd_rn(raw[g].x, __fmul_rn(v[g].x, w));
+                        raw[g].y = __fadd_rn(raw[g].y, __fmul_rn(v[g].y, w));
+                        raw[g].z = __fadd_rn(raw[g].z, __fmul_rn(v[g].z, w));
+                        raw[g].w = __fadd_rn(raw[g].w, __fmul_rn(v[g].w, w));
+                    }
+                }
+        } else {
+            const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+#pragma unroll
+            for (int g = 0; g < K0G; ++g) { raw[2 * g] = row[4 * g]; raw[2 * g + 1] = row[4 * g + 1]; }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): prologue DMAs + table stores
     __syncthreads();
@@ -153,6 +237,11 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
         float psum[OUTC];
 #pragma unroll
         for (int o = 0; o < OUTC; ++o) psum[o] = 0.f;
+        // LAT: the NEXT tile's rows are gathered under this tile's MFMAs -- batch b = (corner b >> 1, channel half b & 1) is issued at the hand-over
+        // of stage LAT_T0 + b and consumed at the next hand-over: 8 registers in flight; accumulators and query record live in LDS
+        lat_f4 lt[2];
+        constexpr int LAT_T0 = 1, LAT_NB = 16;
+        static_assert(!LAT || LAT_T0 + LAT_NB == NSTAGE - 1, "the last batch is consumed at the tile's last hand-over");
         // two accumulator sets: the epilogue of block pair P-1 (VALU) is spread over the MFMAs of the steps that follow it
         f32x16q acc[NSETS][2];
 
@@ -212,14 +301,66 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
             for (int f = 0; f < 4; ++f) A[f] = nA[f];
             if (kg < 3) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + DS_SB) & 3) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + DS_SB) % RING) * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
             } else {
                 // ---- stage hand-over: stage t+1 has landed for everybody, stage t has been read by everybody
                 // VM queue (oldest first): stage t+1, t+2, t+3 [+ the NRAW row loads issued in stage RAW_STAGE]; see the note below
-                if (t > RAW_STAGE && t <= RAW_STAGE + 3) DS_WAIT_VM_LGKM0(8 + NRAW); else DS_WAIT_VM_LGKM0(8);
+                // LAT: VM queue, oldest first, with the corner loads issued BEFORE the stage's DMAs: G(t-3) DMA(t+1) G(t-2) DMA(t+2) G(t-1) DMA(t+3);
+                // the corner issued one hand-over ago must have landed: everything but DMA(t+3)
+                // LAT (3-stage ring, the batch's two loads issued BEFORE the stage's DMAs): G(t-2) DMA(t+1) G(t-1) DMA(t+2) -> everything but DMA(t+2)
+                if (LAT) DS_WAIT_VM_LGKM0(4);
+                else if (t > RAW_STAGE && t <= RAW_STAGE + 3) DS_WAIT_VM_LGKM0(8 + NRAW);
+                else DS_WAIT_VM_LGKM0(8);
                 __builtin_amdgcn_s_barrier();
-                DS_ISSUE((t + 4) % NSTAGE, (t + DS_SB) & 3)
-                if (t == RAW_STAGE) {                                     // next tile's rows (clamped: the last tile re-reads its own)
+                if constexpr (LAT) {
+                    if (t == LAT_T0) {                                    // next tile's query (clamped: the last tile re-samples its own)
+                        long long tn = tile + gridDim.x;
+                        if (tn >= ntiles) tn = tile;
+                        long long m = tn * DS_TILE + wave * 32 + r;
+                        if (m >= p.M) m = p.M - 1;
+                        const LatQuery lq = lat_setup(p, m, h);
+                        lrec[0 * 256 + tid] = lq.goff; lrec[1 * 256 + tid] = lq.ok1;
+                        lrec[2 * 256 + tid] = __float_as_uint(lq.wx0); lrec[3 * 256 + tid] = __float_as_uint(lq.wx1);
+                        lrec[4 * 256 + tid] = __float_as_uint(lq.wy0); lrec[5 * 256 + tid] = __float_as_uint(lq.wy1);
+                        lrec[6 * 256 + tid] = __float_as_uint(lq.wz0); lrec[7 * 256 + tid] = __float_as_uint(lq.wz1);
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) lacc[gg * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if (t >= LAT_T0 && t <= LAT_T0 + LAT_NB) {
+                        __builtin_amdgcn_sched_barrier(0);               // the gather's temporaries live between these two fences only
+                        const unsigned goff = lrec[tid], ok1 = lrec[256 + tid];
+                        if (t > LAT_T0) {                                 // consume batch t - LAT_T0 - 1: accumulators read-modify-written in LDS
+                            const int bb = t - LAT_T0 - 1, c = bb >> 1, half = bb & 1;
+                            asm volatile("" : "+v"(lt[0]));               // first use of the asm loads: behind the hand-over's wait
+                            asm volatile("" : "+v"(lt[1]));
+                            const bool okc = ((c & 1) == 0 || (ok1 & 1u)) && ((c & 2) == 0 || (ok1 & 2u)) && ((c & 4) == 0 || (ok1 & 4u));
+                            // branch-free (a divergent branch here would cut the unrolled MFMA stream into basic blocks): a corner outside the
+                            // volume gets weight 0 on corner 0's (finite) data -- acc + (+-0) == acc exactly, acc is never -0
+                            const float wx = __uint_as_float(lrec[(2 + (c & 1)) * 256 + tid]);
+                            const float wy = __uint_as_float(lrec[(4 + ((c >> 1) & 1)) * 256 + tid]);
+                            const float wz = __uint_as_float(lrec[(6 + (c >> 2)) * 256 + tid]);
+                            const float w = okc ? __fmul_rn(__fmul_rn(wx, wy), wz) : 0.f;
+#pragma unroll
+                            for (int i2 = 0; i2 < 2; ++i2) {
+                                float4 a4 = lacc[(2 * half + i2) * 256 + tid];
+                                a4.x = __fadd_rn(a4.x, __fmul_rn(lt[i2].x, w));
+                                a4.y = __fadd_rn(a4.y, __fmul_rn(lt[i2].y, w));
+                                a4.z = __fadd_rn(a4.z, __fmul_rn(lt[i2].z, w));
+                                a4.w = __fadd_rn(a4.w, __fmul_rn(lt[i2].w, w));
+                                lacc[(2 * half + i2) * 256 + tid] = a4;
+                            }
+                        }
+                        if (t < LAT_T0 + LAT_NB) {                        // issue batch t - LAT_T0 (a corner outside the volume reads corner 0: never used)
+                            const int bb = t - LAT_T0, c = bb >> 1, half = bb & 1;
+                            const bool okc = ((c & 1) == 0 || (ok1 & 1u)) && ((c & 2) == 0 || (ok1 & 2u)) && ((c & 4) == 0 || (ok1 & 4u));
+                            const unsigned off = okc ? goff + (unsigned)((((c >> 2) * p.H + ((c >> 1) & 1)) * p.W + (c & 1)) * 128) : goff;
+                            lat_issue(p.vol, off, half, lt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                DS_ISSUE((t + RING) % NSTAGE, (t + DS_SB) % RING)
+                if (!LAT && t == RAW_STAGE) {                             // next tile's rows (clamped: the last tile re-reads its own)
                     long long tn = tile + gridDim.x;
                     if (tn >= ntiles) tn = tile;
                     long long m = tn * DS_TILE + wave * 32 + r;
@@ -229,7 +370,7 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
                     for (int gg = 0; gg < K0G; ++gg) { raw[2 * gg] = row[4 * gg]; raw[2 * gg + 1] = row[4 * gg + 1]; }
                 }
 #pragma unroll
-                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1 + DS_SB) & 3) * DS_STAGE_BYTES + f * 1024);
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((t + 1 + DS_SB) % RING) * DS_STAGE_BYTES + f * 1024);
             }
             const uint4 b1 = l1 ? x0[0][g % K0G] : h1[0][g], b2 = l1 ? x0[1][g % K0G] : h1[1][g];
             // A: [blk0 w1, blk0 w2, blk1 w1, blk1 w2]; smallest terms first
@@ -263,7 +404,11 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
         }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) epilogue(7, qd);
-        if (!SB_ZERO) sb = (sb + NSTAGE) & 3;
+        if constexpr (LAT) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) raw[gg] = lacc[gg * 256 + tid];      // the next tile's sampled rows
+        }
+        if (!SB_ZERO) sb = (sb + NSTAGE) % RING;
         // ---- output layer: the two lane halves hold disjoint unit sets of the same query
         const long long m = tile * DS_TILE + wave * 32 + r;
 #pragma unroll
@@ -325,6 +470,27 @@ extern "C" int gn_decoder_input_scale(const double *sumsq, int64_t V, int B, int
     return GN_OK;
 }
 
+// The lattice form (the sampler inside the decoder MLP): rows m0 .. m0+M-1 of the (Q,Q,Q) lattice of predict.py:145-147, sampled from the
+// 32-channel channel-last volume by the decoder kernel itself while it multiplies the previous tile -- no sampled-row buffer in HBM.  Folded scalar
+// decoder only ([32, 256, 256, 1]: the volume decoder on the UNet's pre-final volume); bit-identical to gn_trilinear_sample + gn_implicit_decode_split.
+extern "C" int gn_implicit_decode_lattice_split(const float *vol, int D, int H, int W, int C0, int Q, int64_t m0, int64_t M, const void *wpack,
+                                                const float *tab, const float *xscale, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
+    GN_REQUIRE(M >= 0 && ldo >= 1 && OUT == 1 && C0 == 32 && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_lattice_split: the lattice form is packed for the [32, 256, 256, 1] decoder");
+    GN_REQUIRE(D > 0 && H > 0 && W > 0 && (int64_t)D * H * W * 128 < ((int64_t)1 << 32), "gn_implicit_decode_lattice_split: the volume must be addressable with 32-bit byte offsets");
+    GN_REQUIRE(Q > 1 && Q <= 1024 && m0 >= 0 && m0 + M <= (int64_t)Q * Q * Q, "gn_implicit_decode_lattice_split: bad lattice range");
+    if (M == 0) return GN_OK;
+    GN_REQUIRE(vol && wpack && tab && out, "gn_implicit_decode_lattice_split: null pointer");
+    GN_REQUIRE(((uintptr_t)vol & 15) == 0, "gn_implicit_decode_lattice_split: the volume must be 16-byte aligned");
+    DecSplitArgs p;
+    p.xin = nullptr; p.ldxin = 0; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.xscale = xscale; p.out = out; p.ldo = ldo;
+    p.vol = vol; p.D = D; p.H = H; p.W = W; p.Q = Q; p.m0 = m0;
+    const int64_t ntiles = gn_cdiv(M, DS_TILE);
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
+    hipLaunchKernelGGL((implicit_decode_split_kernel<1, 2, true>), dim3(grid), dim3(256), 0, gn_stream(stream), p);
+    GN_LAUNCH_CHECK("gn_implicit_decode_lattice_split");
+    return GN_OK;
+}
+
 extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                                         int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
     GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
@@ -334,6 +500,7 @@ extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, 
     GN_REQUIRE(xin && wpack && tab && out, "gn_implicit_decode_split: null pointer");
     DecSplitArgs p;
     p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.xscale = xscale; p.out = out; p.ldo = ldo;
+    p.vol = nullptr; p.D = p.H = p.W = p.Q = 0; p.m0 = 0;
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
     const int64_t slots = (C0 == 32 && OUT == 1) ? 512 : 256;                       // persistent workgroups: two per CU when they fit (K0G = 2), else one
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);

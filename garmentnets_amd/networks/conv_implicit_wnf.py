@@ -181,6 +181,12 @@ class ImplicitWNFDecoder(PackedModule):
         if layers is None:
             layers = self.packed() if self.fused else None
         split = layers is not None and layers[3] is not None and arith.decode_mode == "f16x2"
+        if query is None and split and arith.fused_lattice and ops.lattice_split_supported(vol_b, layers[3]):
+            # the lattice sampler inside the decoder kernel -- one launch per garment, no sampled-row buffer
+            ops.implicit_decode_lattice_split(vol_b, Q, layers[3], out, xscale=xscale)
+            if xscale is not None:          # garments the device marked unsafe for fp16 planes: the gated fp32 twin samples for itself
+                ops.implicit_decode(vol_b, layers[:3], Q=Q, m0=0, M=M, out=out, run_if=xscale[2:3])
+            return
         chunk = self.ROWS_PER_CHUNK
         if query is None:                           # lattice: whole i-slabs per chunk (the brick sampler's unit)
             chunk = max(1, chunk // (Q * Q)) * Q * Q

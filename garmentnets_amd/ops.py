@@ -583,6 +583,21 @@ def implicit_decode_split(xin, pack, out=None, xscale=None):
     return out
 
 
+def implicit_decode_lattice_split(vol_b, Q, pack, out, xscale=None, m0=0, M=None):
+    """rows m0 .. m0+M-1 of the (Q,Q,Q) lattice through the folded scalar decoder, sampled INSIDE the decoder kernel from the channel-last
+    volume vol_b [D][H][W][32] (no sampled-row buffer); bit-identical to trilinear_sample + implicit_decode_split"""
+    D, H, W, C0 = vol_b.shape
+    M = Q * Q * Q - m0 if M is None else M
+    _lib.call("gn_implicit_decode_lattice_split", _p(_chk(vol_b, torch.float32, "vol")), D, H, W, C0, int(Q), int(m0), int(M), _p(pack.wpack), _p(pack.tab),
+              _p(xscale), 256, 256, pack.out_channels, _p(out), rows_view(out)[1], _stream())
+    return out
+
+
+def lattice_split_supported(vol_b, pack):
+    D, H, W, C0 = vol_b.shape
+    return C0 == 32 and pack.out_channels == 1 and D * H * W * 128 < 2 ** 32 and vol_b.is_contiguous()
+
+
 # ------------------------------------------------------------------------------------------------ isosurface
 def _ggm_tmp(shape, sigma, device):
     """the 8-pass form's workspace; None for the fused launch (kernel radius <= 2: csrc/iso.hip GGM_R)"""

@@ -311,6 +311,14 @@ int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, con
 int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                              int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream);
 
+/* gn_implicit_decode_split with the lattice sampler INSIDE the decoder kernel (reference call site
+ * networks/conv_implicit_wnf.py:137-149 under the lattice loop of predict.py:145-157): rows m0 .. m0+M-1 of the (Q,Q,Q) lattice are sampled
+ * (trilinear, border, align_corners: gn_trilinear_sample's arithmetic) from the channel-last volume vol [D][H][W][32] by the kernel that
+ * multiplies them -- the next tile's corner gathers ride under the current tile's MFMAs; no sampled-row buffer exists.  Folded scalar decoder
+ * only ([32, 256, 256, 1]); D*H*W*128 < 2^32.  Bit-identical to gn_trilinear_sample + gn_implicit_decode_split. */
+int gn_implicit_decode_lattice_split(const float *vol, int D, int H, int W, int C0, int Q, int64_t m0, int64_t M, const void *wpack,
+                                     const float *tab, const float *xscale, int N1, int N2, int OUT, float *out, int ldo, void *stream);
+
 /* Input scale of gn_implicit_decode_split for B garments from the per-(sample, channel) sums of squares [B][C] (fp64) of the volume
  * the rows are sampled from (V voxels per channel; the statistics gn_conv3d_gcr* emit): s = 2^k with (largest channel rms) * s in
  * [1, 2), clamped to smax (pack_decode_split: keeps the scaled biases below 2^13).  out4: [B][4] = {s, 1/s, unsafe, 0}; unsafe = 1
