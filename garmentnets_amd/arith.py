@@ -16,7 +16,9 @@ global mutable state except immutable LUTs).  ``DEFAULT`` is read from the envir
     sparse_first_conv  occupancy-aware launch of the first two encoder convolutions (exact: bit-identical to the dense launch)
     polyphase_upconv   polyphase form of the decoders' first convolutions (csrc/upconv.hip)
     fold_final_conv    the decoders absorb the UNet's final 1x1x1 convolution into their first layer (conv_implicit_wnf.UNetResult)
-    fused_lattice      lattice queries sampled inside the decoder-MLP kernel (no sampled-row buffer in HBM; csrc/decode_split.hip)
+    fused_lattice      lattice queries sampled INSIDE the decoder-MLP kernel (gn_implicit_decode_lattice_split, no sampled-row buffer in
+                       HBM; bit-identical).  OFF by default: measured 16.57 vs 16.48 ms per 16 x 128^3 lattices -- the gather's LDS traffic and the
+                       3-stage weight ring cost the decoder kernel what the separate sampler launch costs
 """
 import dataclasses
 import os
@@ -44,7 +46,7 @@ class Arith:
     sparse_first_conv: bool = True
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
-    fused_lattice: bool = True
+    fused_lattice: bool = False
 
     def __post_init__(self):
         if self.conv_mode not in CONV_MODE_NAMES.values():
@@ -61,7 +63,7 @@ class Arith:
         return cls(conv_mode=CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)],
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
                    sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
-                   fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE"))
+                   fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

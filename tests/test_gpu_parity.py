@@ -603,6 +603,44 @@ def test_lattice_brick_sampler_is_bit_identical(dims, Q, C):
     np.testing.assert_allclose(brick.cpu().numpy(), ref.view(C, -1).t().numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dims,Q", [((16, 16, 16), 16), ((8, 12, 10), 21), ((5, 5, 5), 32), ((32, 32, 32), 48)])
+def test_lattice_sampler_fused_into_the_decoder_is_bit_identical(dims, Q):
+    """SURVEY K14 (gn_implicit_decode_lattice_split: the lattice sampler inside the decoder MLP kernel, the next tile's corner gathers under
+    the current tile's MFMAs, no sampled-row buffer) against gn_trilinear_sample + gn_implicit_decode_split on the same lattice rows: bit for
+    bit -- whole lattices whose size is not a multiple of the 128-row tile, lattices finer and coarser than the volume, border corners
+    (the 5^3 volume: most queries clamp), a row range in the middle of the lattice, and with a per-garment input scale"""
+    D, H, W = dims
+    g = torch.Generator().manual_seed(Q + D)
+    raw = []
+    for i, (n, k) in enumerate(((256, 32), (256, 256), (1, 256))):
+        raw.append((torch.randn(n, k, generator=g) * (2.0 / k) ** 0.5, torch.randn(n, generator=g) * 0.1,
+                    (torch.rand(n, generator=g) + 0.5) if i < 2 else None, torch.randn(n, generator=g) * 0.1 if i < 2 else None))
+    pack = ops.pack_decode_split(raw).to(DEV)
+    vol = (torch.randn(D, H, W, 32, generator=g) * 1.5).to(DEV)
+    n = Q * Q * Q
+    xs = ops.decoder_input_scale((vol.double() ** 2).sum(dim=(0, 1, 2)).view(1, 32), D * H * W, pack.smax)[0]
+    for m0, M, scale in ((0, n, None), (0, n, xs), (Q * Q + 5, min(n - Q * Q - 5, 1000), None)):
+        rows = ops.trilinear_sample(vol, Q=Q, m0=m0, M=M)
+        want = ops.implicit_decode_split(rows, pack, xscale=scale)
+        got = torch.full((M, 1), float("nan"), device=DEV)
+        ops.implicit_decode_lattice_split(vol, Q, pack, got, xscale=scale, m0=m0, M=M)
+        assert torch.equal(got, want), (dims, Q, m0, M)
+
+
+def test_pipeline_with_the_fused_lattice_sampler_equals_the_default(golden_dir):
+    """Arith(fused_lattice=True) through volume_lattice_forward of the whole pipeline == the default two-kernel path, bit for bit"""
+    gd = np.load(os.path.join(golden_dir, "ref_dress_g32.npz"))
+    B, n, G, Q, seed, stride = [int(v) for v in gd["meta"]]
+    model = _model(S.default_hparams(grid=G, reduce_method=str(gd["reduce_method"])), seed)
+    x, pos, batch = S.synthetic_cloud(B, n, seed)
+    data = Batch(sizes=[n] * B, x=x, pos=pos, batch=batch).to(DEV)
+    u3 = model.unet3d_forward(model.pointnet2_forward(data))
+    a = model.volume_lattice_forward(u3, Q)["pred_volume"]
+    b = model.volume_lattice_forward(u3, Q, arith=model.arith.replace(fused_lattice=True))["pred_volume"]
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(b[0].cpu().numpy(), gd["wnf_volume"], rtol=0, atol=TOL)
+
+
 @pytest.fixture(params=["f16x2", "fp32"])
 def decode_mode(request):
     return request.param
