@@ -132,7 +132,13 @@ class KernelTimer:
             vox = float(B) * Dc * Hc * Wc
             return "upconv_partial_kernel", 2.0 * 64 * C1 * cout * vox, (C1 + 8 * cout) * 4.0 * vox + pack.tensor.numel() * 2.0
 
+        def describe_ps(res_, src, prep, *rest, **kw):              # the affine-in-weights form: same kernels, per-sample weight packs
+            B, D, H, W, cin = src.shape
+            vox = float(B) * D * H * W
+            return _lib.load().gn_last_kernel().decode(), 54.0 * cin * prep.cout * vox, (cin + prep.cout) * 4.0 * vox + float(prep.pack.numel())
+
         ops.conv3d_gcr = self._wrap(ops.conv3d_gcr, describe)
+        ops.conv3d_gcr_split_persample = self._wrap(ops.conv3d_gcr_split_persample, describe_ps)
         ops.conv3d_gcr_split = self._wrap(ops.conv3d_gcr_split, describe)
         ops.upconv_partial = self._wrap(ops.upconv_partial, describe_up)
 

@@ -14,6 +14,9 @@ global mutable state except immutable LUTs).  ``DEFAULT`` is read from the envir
                                 G=32 goldens), feature-volume error up to 5e-4
     decode_mode        arithmetic of the decoder MLPs: "f16x2" (csrc/decode_split.hip) or "fp32" (csrc/decode.hip)
     sparse_first_conv  occupancy-aware launch of the first two encoder convolutions (exact: bit-identical to the dense launch)
+    affine_in_weights  (f16x2) the first two encoder convolutions -- whose input is at rest outside the occupied cells' neighbourhood -- take
+                       the GroupNorm affine in per-sample weights + a bias table, so the matrix cores multiply exact zeros there: same MACs,
+                       less power, more clock under the socket cap (csrc/conv_prep.hip).  fp32-class like f16x2 itself
     polyphase_upconv   polyphase form of the decoders' first convolutions (csrc/upconv.hip)
     fold_final_conv    the decoders absorb the UNet's final 1x1x1 convolution into their first layer (conv_implicit_wnf.UNetResult)
     fused_lattice      lattice queries sampled INSIDE the decoder-MLP kernel (gn_implicit_decode_lattice_split, no sampled-row buffer in
@@ -44,6 +47,7 @@ class Arith:
     conv_mode: int = SPLIT_F16X2
     decode_mode: str = "f16x2"
     sparse_first_conv: bool = True
+    affine_in_weights: bool = True
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
     fused_lattice: bool = False
@@ -62,7 +66,8 @@ class Arith:
     def from_env(cls):
         return cls(conv_mode=CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)],
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
-                   sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
+                   sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), affine_in_weights=_env_flag("GARMENTNETS_AFFINE_IN_WEIGHTS"),
+                   polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
                    fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
 
     def replace(self, **kw):

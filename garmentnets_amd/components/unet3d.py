@@ -46,14 +46,21 @@ class SingleConv(PackedModule, nn.Sequential):
             flat      flat cell index of every point gn_grid_scatter scattered into the volume this layer descends from
             reach     1: src0 IS that volume; 2: src0 is the output of the reach-1 layer (non-constant within one voxel of the cells)
             small_in  (reach 2) the reach-1 layer's output over the 5 x 5 x 5 all-zero volume; this call adds 'small_out', its own
-        Only the output tiles that can see an occupied cell (within `reach`) go through the matrix cores; the rest are border-class
-        constants taken from a dense launch of this layer over the 5^3 zero volume with the same affine: bit-identical output."""
+            rest_in   (reach 2) [B][C0]: the value src0 holds away from the cells; this call adds 'rest_out', its own output's
+        arith.sparse_first_conv: only the output tiles that can see an occupied cell (within `reach`) go through the matrix cores; the rest
+        are border-class constants taken from a dense launch of this layer over the 5^3 zero volume with the same affine: bit-identical output.
+        arith.affine_in_weights (f16x2): the GroupNorm affine moves into per-sample weights and a bias table (ops.conv_affine_pack), so that
+        the matrix cores multiply exact zeros wherever src0 is at rest -- same MACs, less power, more clock (csrc/conv_prep.hip)."""
         arith = arith or AR.DEFAULT
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None
         if src1 is not None:
             st1 = stats1 if stats1 is not None else ops.channel_stats(src1)
+        if (sparse is not None and arith.affine_in_weights and arith.conv_mode == ops.SPLIT_F16X2 and src1 is None
+                and src0.shape[-1] % 16 == 0 and self.conv.out_channels % 32 == 0
+                and (sparse["reach"] == 1 or sparse.get("rest_in") is not None)):
+            return self._run_at_rest(src0, st0, with_stats, sparse, arith, gamma, beta)
         if arith.conv_mode != ops.CONV_FP32:      # split-operand path on the 16-bit matrix cores (csrc/unet_split.hip)
             mode = arith.conv_mode
             # fp16 planes: the sample's activations are range-normalised by a power of two (exact, undone in the epilogue)
@@ -66,7 +73,8 @@ class SingleConv(PackedModule, nn.Sequential):
                 cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
             cout, sp = self.conv.out_channels, {}
             if (sparse is not None and arith.sparse_first_conv and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
-                    and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]):
+                    and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]
+                    and (sparse["reach"] == 1 or sparse.get("small_in") is not None)):
                 B, reach = src0.shape[0], int(sparse["reach"])
                 small_in = sparse.get("small_in")
                 if small_in is None:
@@ -104,6 +112,35 @@ class SingleConv(PackedModule, nn.Sequential):
         return ops.conv3d_gcr(src0, src1, a, d, wp, self.conv.out_channels, relu=True), None
 
 
+    def _run_at_rest(self, src0, st0, with_stats, sparse, arith, gamma, beta):
+        """the affine-in-weights form of run() for an input that is at rest (0 for the scattered volume, sparse['rest_in'] behind it) almost
+        everywhere"""
+        B, cout, reach = src0.shape[0], self.conv.out_channels, int(sparse["reach"])
+        a, d = ops.groupnorm_affine(st0, None, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
+        w = self.conv.weight
+        if not w.is_contiguous():
+            w = w.contiguous()
+        prep = ops.conv_affine_pack(w, a, d, st0, sparse.get("rest_in") if reach > 1 else None)
+        # away from the cells the operand is zero: the output is ReLU(0 * scale + K[interior]) = ReLU(K[63]) -- the next layer's rest value
+        sparse["rest_out"] = torch.relu(prep.kbias[:, 63]).contiguous()
+        sp = {}
+        small_in = sparse.get("small_in")
+        if (arith.sparse_first_conv and src0.shape[-1] <= 384 and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * reach
+                and (reach == 1 or small_in is not None)):
+            if small_in is None:
+                small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
+            every = torch.ones((B, 2), dtype=torch.uint8, device=src0.device)
+            ncls = (2 * reach + 1) ** 3
+            dummy = torch.zeros((B, ncls, cout), dtype=torch.float32, device=src0.device)
+            small_out = ops.conv3d_gcr_split_persample(small_in, prep, relu=True, tile_active=every, kconst=dummy, kreach=reach)
+            step = 2 if reach == 1 else 1
+            kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
+            sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
+            sparse["small_out"] = small_out
+        r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, **sp)
+        return r if with_stats else (r, None)
+
+
 class DoubleConv(nn.Sequential):
     def __init__(self, in_channels, out_channels, encoder, kernel_size=3, order="gcr", num_groups=8):
         super().__init__()
@@ -120,7 +157,9 @@ class DoubleConv(nn.Sequential):
         """sparse_flat: src0 is gn_grid_scatter's volume (flat cell index of every scattered point): both convolutions run occupancy-aware"""
         sp1 = dict(flat=sparse_flat, reach=1) if sparse_flat is not None else None
         y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1, arith=arith)
-        sp2 = dict(flat=sparse_flat, reach=2, small_in=sp1["small_out"]) if (sp1 is not None and "small_out" in sp1) else None
+        sp2 = None
+        if sp1 is not None and ("small_out" in sp1 or "rest_out" in sp1):
+            sp2 = dict(flat=sparse_flat, reach=2, small_in=sp1.get("small_out"), rest_in=sp1.get("rest_out"))
         return self.SingleConv2.run(y, None, st, sparse=sp2, arith=arith)
 
 

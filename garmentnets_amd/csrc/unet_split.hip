@@ -36,6 +36,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // border class of coordinate z on an axis of length D for reach r (see SplitArgs::kreach)
 __device__ __forceinline__ int sp_axis_class(int z, int D, int r) { return z < r ? z : (z >= D - r ? 2 * r - (D - 1 - z) : r); }
+// border mask of coordinate g on an axis of length n for the 3x3x3 taps (see SplitArgs::kbias)
+__device__ __forceinline__ int sp_axis_mask(int g, int n) { return (g > 0 ? 1 : 0) | (g < n - 1 ? 2 : 0); }
 
 struct SplitArgs {
     const float *src0;
@@ -60,6 +62,13 @@ struct SplitArgs {
     // the launch over the full-resolution source then adds partial[b][z>>1][y>>1][x>>1][((z&1)*4 + (y&1)*2 + (x&1)) * Cout + n] before
     // the ReLU.
     const float *partial;
+    // affine-in-weights form (gn_conv_affine_pack, conv_prep.hip): the pack holds one weight set PER SAMPLE (wp_bstride bytes apart; 0 = one
+    // set for the batch), out_scale is [B][Cout] (osc_bstride = Cout; 0 = [Cout]) and the GroupNorm shift arrives as the per-(sample, border
+    // class, output channel) constant kbias[B][64][Cout] added before the ReLU (class = (mz * 4 + my) * 4 + mx, m = (has a previous voxel
+    // on the axis) | (has a next one) << 1; 63 = interior).  The operand is then (x - c) s: exactly zero wherever the layer's input is at rest.
+    const float *kbias;
+    int64_t wp_bstride;
+    int osc_bstride;
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
@@ -111,9 +120,24 @@ __device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const 
 // workgroup-uniform element offset from there (the generic path below spent ~40 instructions per value, five of them quarter-rate
 // integer multiplies, on 64-bit addresses and bounds: 9 % of the 128 -> 128 layer, 25 % of a 32 -> 32 one).  Same arithmetic, same
 // order as the generic path: value * scale (+ polyphase partial) (ReLU), channel statistics accumulated q = 0 .. 15.
-__device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32x16s &val, float osc, float *ob, const float *pb, double &ssum, double &ssq) {
+// kb: NULL or this lane's column of the sample's kbias table (class stride Cout); interior tiles (workgroup-uniform) add the one class-63
+// constant, tiles on a face of the volume look the class of each voxel up (gz: the fragment's plane; gy, gx: its first row / column).
+__device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32x16s &val, float osc, float *ob, const float *pb, double &ssum, double &ssq,
+                                                   const float *kb = nullptr, bool interior = true, int gz = 0, int gy = 0, int gx = 0) {
     const int64_t rs = (int64_t)p.W * p.Cout;
     float pv[16];
+    float kv[16];
+    if (kb) {
+        if (interior) {
+            const float k63 = kb[63 * (int64_t)p.Cout];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) kv[q] = k63;
+        } else {
+            const int mz = sp_axis_mask(gz, p.D);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) kv[q] = kb[(int64_t)((mz * 4 + sp_axis_mask(gy + (q >> 2), p.H)) * 4 + sp_axis_mask(gx + (q & 3), p.W)) * p.Cout];
+        }
+    }
     if (pb) {
         const int64_t prs = (int64_t)(p.W >> 1) * 8 * p.Cout;
 #pragma unroll
@@ -126,6 +150,7 @@ __device__ __forceinline__ void sp_store_frag_full(const SplitArgs &p, const f32
     for (int q = 0; q < 16; ++q) {
         const int j = q >> 2, k = q & 3;
         float v = __fmul_rn(val[q], osc);
+        if (kb) v = __fadd_rn(v, kv[q]);
         if (pb) v = __fadd_rn(v, pv[q]);
         if (p.relu) v = gn_relu(v);
         ob[j * rs + (int64_t)k * p.Cout] = v;
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     // every wave issues CH 1-KB pieces per step -- when NT*P is not a multiple of 4 some pieces are fetched twice, harmlessly, so
     // that the s_waitcnt counts are the same in every wave) and read back in lane order (conflict-free b128).
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;                          // bytes per (slice, tap) step
-    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + lane * 16;
+    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)b * p.wp_bstride + (int64_t)cb * BTAP + lane * 16;
     int jf = 0;                                     // flat step index s*27 + tap of the NEXT step to fetch
 #define SP_ISSUE_B()                                                                                                           \
     do {                                                                                                                       \
@@ -394,18 +419,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
     const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
+    const bool interior = z0 > 0 && z0 + TZ < p.D && y0 > 0 && y0 + SP_TY < p.H && x0 > 0 && x0 + SP_TX < p.W;   // no voxel of the tile on a face
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int t = f & 1, gz = z0 + wave + 4 * (f >> 1);
             const int n = n0 + u * 32 + r;
-            const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+            const float osn = p.out_scale[(int64_t)b * p.osc_bstride + n];
+            const float osc = p.act_inv ? __fmul_rn(osn, p.act_inv[b]) : osn;
+            const float *kb = p.kbias ? p.kbias + (int64_t)b * 64 * p.Cout + n : nullptr;
             if (full) {
                 const int gy = y0 + t * 4, gx = x0 + 4 * h;
                 float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n;
                 const float *pb = p.partial ? p.partial + ((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((gz & 1) * 4 * p.Cout + n) : nullptr;
-                sp_store_frag_full(p, tot[f][u], osc, ob, pb, ssum[u], ssq[u]);
+                sp_store_frag_full(p, tot[f][u], osc, ob, pb, ssum[u], ssq[u], kb, interior, gz, gy, gx);
                 continue;
             }
 #pragma unroll
@@ -420,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(tot[f][u][q], osc);
+                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
                         if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
@@ -508,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
     const int nslices = Cin / SP_KS, ngroups = nslices * 9;
     const int64_t bstep = (int64_t)ncb * P * 1024;                                    // bytes per (slice, tap) step of the pack
     // piece k of a group = tap 3g + (k >> 1), plane k & 1; wave w fetches pieces w and w + 4 (waves 0, 1 only)
-    const unsigned char *bg0 = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * (P * 1024) + lane * 16;
+    const unsigned char *bg0 = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)b * p.wp_bstride + (int64_t)cb * (P * 1024) + lane * 16;
     int G = 0;                                       // flat group index s * 9 + g of the group about to be multiplied
     auto issue_group = [&](int g) {
         const unsigned char *src = bg0 + (int64_t)(3 * g) * bstep;
@@ -611,8 +640,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
     // ---- epilogue: fragment xo of this wave = rows (zr = q >> 2, yr = (q & 3) + 4 h) at x = x0 + xw + xo, lane r = channel
     double ssum = 0.0, ssq = 0.0;                   // fp64 per lane (see conv3d_split_kernel)
     const int n = n0 + r;
-    const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+    const float osn = p.out_scale[(int64_t)b * p.osc_bstride + n];
+            const float osc = p.act_inv ? __fmul_rn(osn, p.act_inv[b]) : osn;
     const bool full = !inactive && z0 + T <= p.D && y0 + T <= p.H && x0 + T <= p.W;       // (workgroup-uniform)
+    const bool interior = z0 > 0 && z0 + T < p.D && y0 > 0 && y0 + T < p.H && x0 > 0 && x0 + T < p.W;
+    const float *kb = p.kbias ? p.kbias + (int64_t)b * 64 * p.Cout + n : nullptr;
     if (full) {
         const int64_t rs = (int64_t)p.W * p.Cout, zs_ = (int64_t)p.H * rs;
         const int gz0 = z0 + zw, gy0 = y0 + 4 * h;
@@ -630,9 +662,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
                     pv[q] = pb[(zr >> 1) * pzs + (yq >> 1) * prs + (int64_t)((zr & 1) * 4 + (yq & 1) * 2) * p.Cout];
                 }
             }
+            float kv[16];
+            if (kb) {
+                if (interior) {
+                    const float k63 = kb[63 * (int64_t)p.Cout];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) kv[q] = k63;
+                } else {
+                    const int xmask = sp_axis_mask(gx, p.W);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) kv[q] = kb[(int64_t)((sp_axis_mask(gz0 + (q >> 2), p.D) * 4 + sp_axis_mask(gy0 + (q & 3), p.H)) * 4 + xmask) * p.Cout];
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 float v = __fmul_rn(tot[xo][q], osc);
+                if (kb) v = __fadd_rn(v, kv[q]);
                 if (p.partial) v = __fadd_rn(v, pv[q]);
                 if (p.relu) v = gn_relu(v);
                 ob[(q >> 2) * zs_ + (q & 3) * rs] = v;
@@ -654,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(tot[xo][q], osc);
+                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
                         if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
@@ -735,7 +781,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
     const int piece = wave;
-    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)cb * BTAP + piece * 1024 + lane * 16;
+    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)b * p.wp_bstride + (int64_t)cb * BTAP + piece * 1024 + lane * 16;
     int jf = 0;
 #define SPW_ISSUE_B()                                                                                                          \
     do {                                                                                                                       \
@@ -905,17 +951,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
     const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
+    const bool interior = z0 > 0 && z0 + TZ < p.D && y0 > 0 && y0 + SP_TY < p.H && x0 > 0 && x0 + SP_TX < p.W;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             const int n = n0 + u * 32 + r;
-            const float osc = p.act_inv ? __fmul_rn(p.out_scale[n], p.act_inv[b]) : p.out_scale[n];
+            const float osn = p.out_scale[(int64_t)b * p.osc_bstride + n];
+            const float osc = p.act_inv ? __fmul_rn(osn, p.act_inv[b]) : osn;
+            const float *kb = p.kbias ? p.kbias + (int64_t)b * 64 * p.Cout + n : nullptr;
             if (full) {
                 const int gy = y0 + t * 4, gx = x0 + 4 * h;
                 float *ob = p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n;
                 const float *pb = p.partial ? p.partial + ((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + ((gz & 1) * 4 * p.Cout + n) : nullptr;
-                sp_store_frag_full(p, tot[t][u], osc, ob, pb, ssum[u], ssq[u]);
+                sp_store_frag_full(p, tot[t][u], osc, ob, pb, ssum[u], ssq[u], kb, interior, gz, gy, gx);
                 continue;
             }
 #pragma unroll
@@ -930,6 +979,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                         v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
                     } else {
                         v = __fmul_rn(tot[t][u][q], osc);
+                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
                         if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
                         if (p.relu) v = gn_relu(v);
                     }
@@ -958,10 +1008,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     }
 }
 
-extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
-                                   const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
-                                   int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                                   const float *kconst, int kreach, const float *partial, void *stream) {
+static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
+                                 const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
+                                 int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
+                                 const float *kconst, int kreach, const float *partial, const float *kbias, int64_t wp_bstride, int osc_bstride,
+                                 void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -978,6 +1029,7 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
     p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach; p.partial = partial;
+    p.kbias = kbias; p.wp_bstride = wp_bstride; p.osc_bstride = osc_bstride;
     GN_REQUIRE(!partial || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: a polyphase partial needs even dims");
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);
@@ -1022,4 +1074,25 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
 #undef SP_LAUNCH
     GN_LAUNCH_CHECK("gn_conv3d_gcr_split");
     return GN_OK;
+}
+
+extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
+                                   const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
+                                   int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
+                                   const float *kconst, int kreach, const float *partial, void *stream) {
+    return conv3d_gcr_split_impl(src0, C0, src1, C1, a, d, wp_planes, mode, out_scale, act_inv_scale, B, D, H, W, Cout, relu, out, out_sum, out_sumsq,
+                                 tile_active, kconst, kreach, partial, nullptr, 0, 0, stream);
+}
+
+// The affine-in-weights form: everything gn_conv_affine_pack (conv_prep.hip) prepared for this batch -- the staging affine (s, -c s), the
+// per-sample fp16x2 weight packs, their [B][Cout] output scales and the [B][64][Cout] bias table.  Same kernels, same dispatch.
+extern "C" int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
+                                             const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                                             double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
+                                             void *stream) {
+    GN_REQUIRE(kbias != nullptr && pack != nullptr, "gn_conv3d_gcr_split_persample: pack and kbias are required");
+    GN_REQUIRE(Cin > 0 && Cin % SP_KS == 0 && Cout > 0 && Cout % 32 == 0, "gn_conv3d_gcr_split_persample: channel counts must be multiples of 16 (in) / 32 (out)");
+    const int64_t per_sample = (int64_t)(Cin / SP_KS) * 27 * (Cout / 32) * 2 * 1024;
+    return conv3d_gcr_split_impl(src, Cin, nullptr, 0, stage_a, stage_d, pack, GN_SPLIT_F16X2, out_scale, nullptr, B, D, H, W, Cout, relu, out, out_sum,
+                                 out_sumsq, tile_active, kconst, kreach, nullptr, kbias, per_sample, Cout, stream);
 }

@@ -418,6 +418,51 @@ def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, 
     return (out, (s, q, D * H * W)) if with_stats else out
 
 
+class AffinePack:
+    """what gn_conv_affine_pack prepared for ONE batch of one 'gcr' layer: per-sample fp16x2 weight sets with the GroupNorm affine folded
+    in, the staging affine (s, -c s), the output scales and the border-class bias table"""
+    __slots__ = ("pack", "stage_a", "stage_d", "out_scale", "kbias", "cin", "cout")
+
+
+def conv_affine_pack(weight, a, d, stats, rest=None):
+    """weight: the raw Conv3d weight [Cout][Cin][3][3][3] (fp32, device); a, d [B][Cin]: the GroupNorm affine (groupnorm_affine without the
+    sample scale); stats = (sum, sumsq, V) of the layer's input; rest [B][Cin] or None (zeros): the value the input holds away from its
+    support -> AffinePack (csrc/conv_prep.hip)"""
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    B, dev = a.shape[0], a.device
+    w = weight.detach()
+    _chk(w, torch.float32, "weight")
+    _chk(a, torch.float32, "a"); _chk(d, torch.float32, "d")
+    if rest is not None:
+        _chk(rest, torch.float32, "rest")
+        assert tuple(rest.shape) == (B, cin)
+    nbytes = _lib.load().gn_conv_affine_pack_bytes(B, cin, cout)
+    if nbytes == 0 and B > 0:
+        raise ValueError("conv_affine_pack: channel counts must be multiples of 16 (in) / 32 (out)")
+    r = AffinePack()
+    r.cin, r.cout = cin, cout
+    r.pack = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    r.stage_a = torch.empty((B, cin), dtype=torch.float32, device=dev)
+    r.stage_d = torch.empty((B, cin), dtype=torch.float32, device=dev)
+    r.out_scale = torch.empty((B, cout), dtype=torch.float32, device=dev)
+    r.kbias = torch.empty((B, 64, cout), dtype=torch.float32, device=dev)
+    ws = torch.empty((B * cin * 12 + B * cout * 4 + 16,), dtype=torch.uint8, device=dev)
+    _lib.call("gn_conv_affine_pack", _p(w), cin, cout, _p(a), _p(d), _p(stats[0]), _p(stats[1]), int(stats[2]), _p(rest), B, _p(r.pack), nbytes,
+              _p(r.stage_a), _p(r.stage_d), _p(r.out_scale), _p(r.kbias), _p(ws), ws.numel(), _stream())
+    return r
+
+
+def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_active=None, kconst=None, kreach=1):
+    """the 'gcr' layer from an AffinePack (GN_SPLIT_F16X2 arithmetic; the operand is exactly zero wherever the input is at rest)"""
+    B, D, H, W, C = src.shape
+    assert C == prep.cin and B == prep.stage_a.shape[0]
+    out = torch.empty((B, D, H, W, prep.cout), dtype=torch.float32, device=src.device)
+    s, q = _stats_buffers(B, prep.cout, src.device, with_stats)
+    _lib.call("gn_conv3d_gcr_split_persample", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), _p(prep.kbias),
+              B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _stream())
+    return (out, (s, q, D * H * W)) if with_stats else out
+
+
 def _stats_buffers(B, C, device, want):
     if not want:
         return None, None

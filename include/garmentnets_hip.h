@@ -202,6 +202,31 @@ int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, co
                         int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
                         const float *kconst, int kreach, const float *partial, void *stream);
 
+/* The GroupNorm affine folded into PER-SAMPLE weights (csrc/conv_prep.hip) -- for a 'gcr' layer (components/unet3d.py:66-76) whose input
+ * is AT REST almost everywhere: the scattered volume of networks/conv_implicit_wnf.py:92-94 (zero outside the occupied cells) and the
+ * layer behind it (one value per channel away from them).  conv(a x + d) is linear, so with c = the rest value (coff [B][Cin]; NULL =
+ * zeros) and s a per-(sample, channel) power of two
+ *     conv_w(a x + d)[n] = sum_taps sum_ch (w a / s) ((x - c) s)  +  sum_{taps inside the volume} sum_ch w (a c + d):
+ * the operand (x - c) s is EXACTLY ZERO wherever x == c, the shift becomes the per-(sample, border class, output channel) constant kbias.
+ * Same MACs through the same kernels; the matrix cores see mostly zeros and draw less power, which under the socket power cap is clock
+ * (DESIGN.md 5.1).  gn_conv_affine_pack prepares, from the raw Conv3d weight w [Cout][Cin][3][3][3], the GroupNorm affine a, d [B][Cin]
+ * (gn_groupnorm_affine without the sample scale) and the input's statistics sum / sumsq [B][Cin] over V voxels:
+ *     stage_a, stage_d [B][Cin]  the staging affine (s, -c s), s = 2^k with rms(x - c) s in [1, 2)
+ *     pack                       [B] fp16x2 weight sets (w a / s, row-scaled to [1, 2)) in the fragment order of gn_conv3d_gcr_split,
+ *                                gn_conv_affine_pack_bytes(B, Cin, Cout) bytes
+ *     out_scale [B][Cout]        exact powers of two undoing the row scales
+ *     kbias [B][64][Cout]        class = (mz * 4 + my) * 4 + mx, m = (voxel has a previous neighbour on the axis) | (a next one) << 1
+ * ws: B * Cin * 12 + B * Cout * 4 bytes.  gn_conv3d_gcr_split_persample runs the layer from them (GN_SPLIT_F16X2 arithmetic, one source;
+ * tile_active / kconst / kreach as gn_conv3d_gcr_split). */
+size_t gn_conv_affine_pack_bytes(int B, int Cin, int Cout);
+int gn_conv_affine_pack(const float *w, int Cin, int Cout, const float *a, const float *d, const double *sum, const double *sumsq, int64_t V,
+                        const float *coff, int B, void *pack, size_t pack_bytes, float *stage_a, float *stage_d, float *out_scale,
+                        float *kbias, void *ws, size_t ws_bytes, void *stream);
+int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
+                                  const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                                  double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
+                                  void *stream);
+
 /* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
  * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27
  * fine taps merge into 8 coarse taps per output parity class (sums of weights, host side, fp64) -- 8/27 of the MACs of those channels,

@@ -1015,8 +1015,8 @@ def test_sa_fused_runs_in_the_pipeline(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ occupancy-aware first convolution
-@pytest.mark.parametrize("G,mode", [(32, 4), (36, 4), (20, 2)])
-def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
+@pytest.mark.parametrize("G,mode,aiw", [(32, 4, True), (36, 4, True), (32, 4, False), (36, 4, False), (20, 2, False)])
+def test_sparse_first_conv_is_bit_identical_to_dense(G, mode, aiw):
     """the first TWO UNet convolutions behind a scattered volume (the encoder's first DoubleConv, 128 -> 128 -> 32): only the tiles that
     can see an occupied cell (within 1 voxel for the first layer, 2 for the second) go through the matrix cores, the rest are
     border-class constants (csrc/unet_split.hip tile_active / kconst / kreach).  Both outputs must equal the dense launches bit for
@@ -1034,16 +1034,24 @@ def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
     dc = DoubleConv(C, 32, encoder=True)                                   # 128 -> 128 -> 32, the shipped encoders.0
     dc.load_state_dict({k: S.synthetic_tensor("c." + k, tuple(v.shape), 1) for k, v in dc.state_dict().items()})
     dc = dc.to(DEV)
-    a_sp = AR.DEFAULT.replace(conv_mode=mode, sparse_first_conv=True)
+    # aiw: both layers in the affine-in-weights form (arith.affine_in_weights: per-sample weight packs + bias table, csrc/conv_prep.hip) --
+    # the occupancy-aware launch must equal ITS dense launch bit for bit just the same
+    a_sp = AR.DEFAULT.replace(conv_mode=mode, sparse_first_conv=True, affine_in_weights=aiw)
     a_dn = a_sp.replace(sparse_first_conv=False)
     sp1 = dict(flat=flat.to(DEV), reach=1)
     y1_s, st1_s = dc.SingleConv1.run(vol, None, stats, None, sparse=sp1, arith=a_sp)
-    y2_s, st2_s = dc.SingleConv2.run(y1_s, None, st1_s, sparse=dict(flat=flat.to(DEV), reach=2, small_in=sp1["small_out"]), arith=a_sp)
+    assert ("rest_out" in sp1) == aiw
+    y2_s, st2_s = dc.SingleConv2.run(y1_s, None, st1_s, sparse=dict(flat=flat.to(DEV), reach=2, small_in=sp1["small_out"], rest_in=sp1.get("rest_out")),
+                                     arith=a_sp)
     both_s, _ = dc.run(vol, None, stats, None, sparse_flat=flat.to(DEV), arith=a_sp)
-    y1_d, st1_d = dc.SingleConv1.run(vol, None, stats, None, arith=a_dn)
+    d1 = dict(flat=flat.to(DEV), reach=1)
+    y1_d, st1_d = dc.SingleConv1.run(vol, None, stats, None, sparse=d1, arith=a_dn)
+    assert "small_out" not in d1
     # (layer 2's GroupNorm affine from the SAME statistics in both forms: the two launches' fp64 atomic sums agree to 1 ulp only, which
     #  once in a while lands on the other side of an fp32 rounding boundary of the affine -- that is the atomics' order, not the kernels)
-    y2_d, st2_d = dc.SingleConv2.run(y1_d, None, st1_s, arith=a_dn)
+    y2_d, st2_d = dc.SingleConv2.run(y1_d, None, st1_s, sparse=dict(flat=flat.to(DEV), reach=2, rest_in=d1.get("rest_out")), arith=a_dn)
+    if aiw:            # the garment without a point is at rest everywhere: every interior voxel of layer 1's output IS the rest value
+        assert torch.equal(y1_d[1, 3, 4, 5], d1["rest_out"][1]) and torch.equal(y1_d[1, G // 2, G // 2, G // 2], d1["rest_out"][1])
     f1, f2 = ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 1), ops.grid_tile_flags(flat.to(DEV), B, (G, G, G), 2)
     a1, a2 = f1.sum(dim=1).tolist(), f2.sum(dim=1).tolist()
     print(f"G={G} mode={mode}: active tiles per garment, layer 1 {a1} / layer 2 {a2} of {f1.shape[1]}")
@@ -1053,6 +1061,80 @@ def test_sparse_first_conv_is_bit_identical_to_dense(G, mode):
     for (s_s, q_s, _), (s_d, q_d, _) in ((st1_s, st1_d), (st2_s, st2_d)):
         assert float(((s_s - s_d).abs() / s_d.abs().clamp_min(1e-30)).max()) <= 1e-13 and float(((q_s - q_d).abs() / q_d.abs().clamp_min(1e-30)).max()) <= 1e-13
     assert bool(torch.isfinite(y2_s).all()) and float(y2_s.abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm affine in per-sample weights
+@pytest.mark.parametrize("Cin,Cout,dims,B,kind", [(32, 128, (32, 32, 32), 4, "scattered"), (32, 64, (64, 64, 32), 2, "scattered"),
+                                                  (32, 32, (64, 64, 64), 1, "scattered"), (16, 32, (5, 7, 9), 2, "dense"),
+                                                  (128, 32, (16, 16, 16), 2, "offset"), (64, 96, (12, 20, 9), 3, "dense"),
+                                                  (32, 32, (64, 64, 64), 1, "offset")])
+def test_affine_in_weights_conv_against_fp64(Cin, Cout, dims, B, kind):
+    """GroupNorm -> Conv3d -> ReLU (components/unet3d.py:66-76) with the affine folded into per-sample weights and a border-class bias table
+    (gn_conv_affine_pack + gn_conv3d_gcr_split_persample): exact algebra for ANY rest value c, so it is checked on a scattered volume
+    (c = 0), on a volume at a per-channel offset with a few cells disturbed (c = that offset) and on dense noise (c = 0, nothing at
+    rest), against torch in fp64 and against the standard f16x2 form.  Shapes chosen to reach every kernel variant (128-wide, 64-wide,
+    x-strip, 32-wide with ragged tiles)."""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + dims[0])
+    D, H, W = dims
+    rest = None
+    if kind == "dense":
+        x = torch.randn(B, D, H, W, Cin, generator=g) * 1.7 + 0.3
+    else:
+        x = torch.zeros(B, D, H, W, Cin)
+        if kind == "offset":
+            rest = torch.rand(B, Cin, generator=g) * 2.0
+            rest[:, ::5] = 0.0                                    # ReLU outputs: some channels rest at zero
+            x = x + rest[:, None, None, None, :]
+        n = max(8, D * H * W // 400)
+        for b in range(B - 1):                                    # the last garment has no point at all
+            idx = torch.stack([torch.randint(0, D, (n,), generator=g), torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g)], 1)
+            idx[0] = torch.tensor([0, 0, 0]); idx[1] = torch.tensor([D - 1, H - 1, W - 1])
+            x[b, idx[:, 0], idx[:, 1], idx[:, 2]] = torch.randn(n, Cin, generator=g).abs() * 3.0
+    conv = SingleConv(Cin, Cout)
+    conv.load_state_dict({k: S.synthetic_tensor("aw." + k, tuple(v.shape), 3) for k, v in conv.state_dict().items()})
+    xd = x.permute(0, 4, 1, 2, 3).double()
+    ref = F.relu(F.conv3d(F.group_norm(xd, conv.groupnorm.num_groups, conv.groupnorm.weight.double(), conv.groupnorm.bias.double(), eps=1e-5),
+                          conv.conv.weight.double(), None, padding=1)).permute(0, 2, 3, 4, 1)
+    conv = conv.to(DEV)
+    xg = x.to(DEV)
+    fake_flat = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    a_new = AR.DEFAULT.replace(conv_mode=4, sparse_first_conv=False, affine_in_weights=True)
+    sp = dict(flat=fake_flat, reach=1) if rest is None else dict(flat=fake_flat, reach=2, rest_in=rest.to(DEV))
+    y_new, (s_new, q_new, V) = conv.run(xg, None, sparse=sp, arith=a_new)
+    kern = ops._lib.load().gn_last_kernel().decode()
+    assert "rest_out" in sp
+    y_old, (s_old, q_old, _) = conv.run(xg, None, arith=a_new.replace(affine_in_weights=False))
+    scale = float(ref.abs().max())
+    e_new, e_old = float((y_new.cpu().double() - ref).abs().max()), float((y_old.cpu().double() - ref).abs().max())
+    print(f"{Cin}->{Cout} {dims} B={B} {kind}: err vs fp64 affine-in-weights {e_new:.2e} / standard {e_old:.2e} (max |y| {scale:.2f}); kernel {kern}")
+    assert e_new <= 2e-5 * max(1.0, scale) and e_new <= 2 * max(e_old, 2e-6 * max(1.0, scale))
+    # the epilogue statistics are those of the stored values
+    assert float((s_new.cpu() - y_new.double().sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(s_new.abs().max()))
+    assert float((q_new.cpu() - (y_new.double() ** 2).sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(q_new.abs().max()))
+    if kind != "dense" and min(dims) >= 12:
+        # a garment at rest: interior voxels hold exactly the rest value this layer reports for the next one
+        assert torch.equal(y_new[B - 1, D // 2, H // 2, W // 2], sp["rest_out"][B - 1])
+    assert bool(torch.isfinite(y_new).all())
+
+
+def test_affine_in_weights_pipeline_equals_standard_form_to_fp32_class(golden_dir):
+    """the whole dense phase with and without arith.affine_in_weights: the feature volume and the WNF agree to fp32-class error (the two
+    forms round differently, neither is the reference), occupancy-aware or not"""
+    hp = S.default_hparams(grid=32)
+    model = _model(hp, 3)
+    x, pos, batch = S.synthetic_cloud(2, 3000, 5)
+    p2 = model.pointnet2_forward(Batch(sizes=[3000] * 2, x=x, pos=pos, batch=batch).to(DEV))
+    outs = {}
+    for aiw in (True, False):
+        for sparse in (True, False):
+            ar = AR.DEFAULT.replace(affine_in_weights=aiw, sparse_first_conv=sparse)
+            outs[(aiw, sparse)] = model.unet3d_forward(p2, arith=ar)["out_feature_volume"].float().clone()
+    assert torch.equal(outs[(True, True)], outs[(True, False)]) and torch.equal(outs[(False, True)], outs[(False, False)])
+    scale = float(outs[(False, False)].abs().max())
+    err = float((outs[(True, False)] - outs[(False, False)]).abs().max())
+    print(f"feature volume: affine-in-weights vs standard {err:.2e} (max |v| {scale:.2f})")
+    assert err <= 2e-5 * max(1.0, scale)
 
 
 # ------------------------------------------------------------------------------------------------ polyphase decoder convolutions
