@@ -39,7 +39,7 @@ PROTOTYPES = {
     "gn_conv3d_gcr_split": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "gn_conv_affine_pack_bytes": [_i32, _i32, _i32],
     "gn_conv_affine_pack": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
-    "gn_conv3d_gcr_split_persample": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "gn_conv3d_gcr_split_persample": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "gn_upconv_partial": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_grid_tile_flags": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],

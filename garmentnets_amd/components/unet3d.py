@@ -39,7 +39,7 @@ class SingleConv(PackedModule, nn.Sequential):
         wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
         return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None, arith=None):
+    def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None, arith=None, rest0=None):
         """arith: the arith.Arith of this call (None: arith.DEFAULT).  src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
         stats0/stats1: (sum, sumsq, V) of the inputs when the producing kernel already emitted them.
         sparse: occupancy-aware launch (split-operand modes), a dict
@@ -50,7 +50,9 @@ class SingleConv(PackedModule, nn.Sequential):
         arith.sparse_first_conv: only the output tiles that can see an occupied cell (within `reach`) go through the matrix cores; the rest
         are border-class constants taken from a dense launch of this layer over the 5^3 zero volume with the same affine: bit-identical output.
         arith.affine_in_weights (f16x2): the GroupNorm affine moves into per-sample weights and a bias table (ops.conv_affine_pack), so that
-        the matrix cores multiply exact zeros wherever src0 is at rest -- same MACs, less power, more clock (csrc/conv_prep.hip)."""
+        the matrix cores multiply exact zeros wherever src0 is at rest -- same MACs, less power, more clock (csrc/conv_prep.hip).
+        rest0 [B][C0]: (polyphase form of a decoder layer) the value the skip connection src0 holds away from the cells: its full-resolution
+        launch takes the affine-in-weights form as well."""
         arith = arith or AR.DEFAULT
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
@@ -101,6 +103,16 @@ class SingleConv(PackedModule, nn.Sequential):
                     cache[pkey] = (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_upconv_weight(wm, cout, mode).to(dev))
                 pk0, pkm = cache[pkey]
                 part = ops.upconv_partial(src1, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, cout, act_inv=act_inv)
+                if rest0 is not None and arith.affine_in_weights and mode == ops.SPLIT_F16X2 and c0 % 16 == 0 and cout % 32 == 0:
+                    # (a, d carry the sample's power-of-two activation scale: exact to undo)
+                    a0 = (a[:, :c0] * act_inv[:, None]).contiguous()
+                    d0 = (d[:, :c0] * act_inv[:, None]).contiguous()
+                    wkey = ("w0",) + key + (c0,)
+                    if wkey not in cache:
+                        cache[wkey] = self.conv.weight.detach()[:, :c0].contiguous()
+                    prep = ops.conv_affine_pack(cache[wkey], a0, d0, st0, rest0)
+                    r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, partial=part)
+                    return r if with_stats else (r, None)
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)
                 return r if with_stats else (r, None)
@@ -153,14 +165,19 @@ class DoubleConv(nn.Sequential):
         self.add_module("SingleConv1", SingleConv(c1_in, c1_out, kernel_size, order, num_groups))
         self.add_module("SingleConv2", SingleConv(c2_in, c2_out, kernel_size, order, num_groups))
 
-    def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None, arith=None):
-        """sparse_flat: src0 is gn_grid_scatter's volume (flat cell index of every scattered point): both convolutions run occupancy-aware"""
+    def run(self, src0, src1=None, stats0=None, stats1=None, sparse_flat=None, arith=None, info=None, rest0=None):
+        """sparse_flat: src0 is gn_grid_scatter's volume (flat cell index of every scattered point): both convolutions run occupancy-aware /
+        in the affine-in-weights form; info: a dict that receives 'rest_out' [B][Cout], the value the block's output holds away from the
+        cells (when that form ran); rest0: that value for src0 of a decoder block (its skip connection)"""
         sp1 = dict(flat=sparse_flat, reach=1) if sparse_flat is not None else None
-        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1, arith=arith)
+        y, st = self.SingleConv1.run(src0, src1, stats0, stats1, sparse=sp1, arith=arith, rest0=rest0)
         sp2 = None
         if sp1 is not None and ("small_out" in sp1 or "rest_out" in sp1):
             sp2 = dict(flat=sparse_flat, reach=2, small_in=sp1.get("small_out"), rest_in=sp1.get("rest_out"))
-        return self.SingleConv2.run(y, None, st, sparse=sp2, arith=arith)
+        r = self.SingleConv2.run(y, None, st, sparse=sp2, arith=arith)
+        if info is not None and sp2 is not None and "rest_out" in sp2:
+            info["rest_out"] = sp2["rest_out"]
+        return r
 
 
 class Encoder(nn.Module):
@@ -169,7 +186,7 @@ class Encoder(nn.Module):
         self.pooling = nn.MaxPool3d(kernel_size=2) if apply_pooling else None
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=True, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, x, stats=None, sparse_flat=None, arith=None):
+    def run(self, x, stats=None, sparse_flat=None, arith=None, info=None):
         if self.pooling is not None:
             sparse_flat = None
             c = x.shape[-1]
@@ -177,7 +194,7 @@ class Encoder(nn.Module):
                 x, stats = ops.maxpool3d_2(x, with_stats=True)
             else:
                 x, stats = ops.maxpool3d_2(x), None
-        return self.basic_module.run(x, None, stats, sparse_flat=sparse_flat, arith=arith)
+        return self.basic_module.run(x, None, stats, sparse_flat=sparse_flat, arith=arith, info=info)
 
 
 class Decoder(nn.Module):
@@ -185,9 +202,9 @@ class Decoder(nn.Module):
         super().__init__()
         self.basic_module = DoubleConv(in_channels, out_channels, encoder=False, order=conv_layer_order, num_groups=num_groups)
 
-    def run(self, encoder_features, x, stats_skip=None, stats_x=None, arith=None):
+    def run(self, encoder_features, x, stats_skip=None, stats_x=None, arith=None, skip_rest=None):
         # cat((encoder_features, upsample_nearest(x)), dim=channel) is never materialised
-        return self.basic_module.run(encoder_features, x, stats_skip, stats_x, arith=arith)
+        return self.basic_module.run(encoder_features, x, stats_skip, stats_x, arith=arith, rest0=skip_rest)
 
 
 class FinalConv1x1(PackedModule, nn.Conv3d):
@@ -226,10 +243,11 @@ class Abstract3DUNet(nn.Module):
         next GroupNorm needs (conv / max-pool epilogues), so no activation is re-read for normalisation."""
         feats = []
         for i, enc in enumerate(self.encoders):
-            x, stats = enc.run(x, stats, sparse_flat=sparse_flat if i == 0 else None, arith=arith)
-            feats.insert(0, (x, stats))
-        for dec, (skip, skip_stats) in zip(self.decoders, feats[1:]):
-            x, stats = dec.run(skip, x, skip_stats, stats, arith=arith)
+            info = {}
+            x, stats = enc.run(x, stats, sparse_flat=sparse_flat if i == 0 else None, arith=arith, info=info)
+            feats.insert(0, (x, stats, info.get("rest_out")))      # rest_out: encoder 0 behind a scattered volume (affine-in-weights form)
+        for dec, (skip, skip_stats, skip_rest) in zip(self.decoders, feats[1:]):
+            x, stats = dec.run(skip, x, skip_stats, stats, arith=arith, skip_rest=skip_rest)
         if pre_final:       # return_stats: + (sum, sumsq, V) of the pre-final volume (the decoders derive their input scale from it)
             return (x, stats) if return_stats else x
         return self.final_conv.run(x)

@@ -1085,14 +1085,15 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
 }
 
 // The affine-in-weights form: everything gn_conv_affine_pack (conv_prep.hip) prepared for this batch -- the staging affine (s, -c s), the
-// per-sample fp16x2 weight packs, their [B][Cout] output scales and the [B][64][Cout] bias table.  Same kernels, same dispatch.
+// per-sample fp16x2 weight packs, their [B][Cout] output scales and the [B][64][Cout] bias table.  Same kernels, same dispatch.  partial:
+// as gn_conv3d_gcr_split (the polyphase form of a decoder layer whose skip connection is at rest away from the cells).
 extern "C" int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
                                              const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                                              double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
-                                             void *stream) {
+                                             const float *partial, void *stream) {
     GN_REQUIRE(kbias != nullptr && pack != nullptr, "gn_conv3d_gcr_split_persample: pack and kbias are required");
     GN_REQUIRE(Cin > 0 && Cin % SP_KS == 0 && Cout > 0 && Cout % 32 == 0, "gn_conv3d_gcr_split_persample: channel counts must be multiples of 16 (in) / 32 (out)");
     const int64_t per_sample = (int64_t)(Cin / SP_KS) * 27 * (Cout / 32) * 2 * 1024;
     return conv3d_gcr_split_impl(src, Cin, nullptr, 0, stage_a, stage_d, pack, GN_SPLIT_F16X2, out_scale, nullptr, B, D, H, W, Cout, relu, out, out_sum,
-                                 out_sumsq, tile_active, kconst, kreach, nullptr, kbias, per_sample, Cout, stream);
+                                 out_sumsq, tile_active, kconst, kreach, partial, kbias, per_sample, Cout, stream);
 }

@@ -452,14 +452,14 @@ def conv_affine_pack(weight, a, d, stats, rest=None):
     return r
 
 
-def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_active=None, kconst=None, kreach=1):
+def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_active=None, kconst=None, kreach=1, partial=None):
     """the 'gcr' layer from an AffinePack (GN_SPLIT_F16X2 arithmetic; the operand is exactly zero wherever the input is at rest)"""
     B, D, H, W, C = src.shape
     assert C == prep.cin and B == prep.stage_a.shape[0]
     out = torch.empty((B, D, H, W, prep.cout), dtype=torch.float32, device=src.device)
     s, q = _stats_buffers(B, prep.cout, src.device, with_stats)
     _lib.call("gn_conv3d_gcr_split_persample", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), _p(prep.kbias),
-              B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _stream())
+              B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 

@@ -217,7 +217,7 @@ int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, co
  *     out_scale [B][Cout]        exact powers of two undoing the row scales
  *     kbias [B][64][Cout]        class = (mz * 4 + my) * 4 + mx, m = (voxel has a previous neighbour on the axis) | (a next one) << 1
  * ws: B * Cin * 12 + B * Cout * 4 bytes.  gn_conv3d_gcr_split_persample runs the layer from them (GN_SPLIT_F16X2 arithmetic, one source;
- * tile_active / kconst / kreach as gn_conv3d_gcr_split). */
+ * tile_active / kconst / kreach / partial as gn_conv3d_gcr_split). */
 size_t gn_conv_affine_pack_bytes(int B, int Cin, int Cout);
 int gn_conv_affine_pack(const float *w, int Cin, int Cout, const float *a, const float *d, const double *sum, const double *sumsq, int64_t V,
                         const float *coff, int B, void *pack, size_t pack_bytes, float *stage_a, float *stage_d, float *out_scale,
@@ -225,7 +225,7 @@ int gn_conv_affine_pack(const float *w, int Cin, int Cout, const float *a, const
 int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
                                   const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                                   double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
-                                  void *stream);
+                                  const float *partial, void *stream);
 
 /* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
  * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27

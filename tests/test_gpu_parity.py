@@ -1137,6 +1137,43 @@ def test_affine_in_weights_pipeline_equals_standard_form_to_fp32_class(golden_di
     assert err <= 2e-5 * max(1.0, scale)
 
 
+def test_polyphase_decoder_conv_with_the_skip_connection_at_rest():
+    """the last decoder's first convolution, cat((skip, upsample(x))) -> gcr: the skip connection is encoder 0's output, at rest away from the
+    cells -- its full-resolution launch takes the affine-in-weights form (SingleConv.run rest0=, the polyphase partial added in the same
+    epilogue) and must agree with the literal polyphase form and with torch in fp64"""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(77)
+    B, C0, C1, Cout, D, H, W = 2, 32, 64, 32, 64, 64, 64
+    rest = torch.rand(B, C0, generator=g) * 1.5
+    rest[:, ::3] = 0.0
+    x0 = torch.zeros(B, D, H, W, C0) + rest[:, None, None, None, :]
+    n = 700
+    idx = torch.stack([torch.randint(0, D, (n,), generator=g), torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g)], 1)
+    idx[0] = torch.tensor([0, 0, 0]); idx[1] = torch.tensor([D - 1, H - 1, W - 1])
+    x0[0, idx[:, 0], idx[:, 1], idx[:, 2]] = torch.randn(n, C0, generator=g).abs() * 2.0          # garment 1 stays at rest everywhere
+    x1 = torch.randn(B, D // 2, H // 2, W // 2, C1, generator=g) * 1.5 + 0.2
+    conv = SingleConv(C0 + C1, Cout)
+    conv.load_state_dict({k: S.synthetic_tensor("pr." + k, tuple(v.shape), 4) for k, v in conv.state_dict().items()})
+    up = F.interpolate(x1.permute(0, 4, 1, 2, 3).double(), size=(D, H, W), mode="nearest")
+    cat = torch.cat((x0.permute(0, 4, 1, 2, 3).double(), up), dim=1)
+    ref = F.relu(F.conv3d(F.group_norm(cat, conv.groupnorm.num_groups, conv.groupnorm.weight.double(), conv.groupnorm.bias.double(), eps=1e-5),
+                          conv.conv.weight.double(), None, padding=1)).permute(0, 2, 3, 4, 1)
+    conv = conv.to(DEV)
+    s0, s1 = x0.to(DEV), x1.to(DEV)
+    y_rest, (sr, qr, _) = conv.run(s0, s1, rest0=rest.to(DEV))
+    kern = ops._lib.load().gn_last_kernel().decode()
+    y_lit, (sl, ql, _) = conv.run(s0, s1)
+    scale = float(ref.abs().max())
+    e_rest, e_lit = float((y_rest.cpu().double() - ref).abs().max()), float((y_lit.cpu().double() - ref).abs().max())
+    print(f"polyphase {C0}+{C1}->{Cout} at {D}^3: err vs fp64 with the skip at rest {e_rest:.2e} / literal {e_lit:.2e} (max |y| {scale:.2f}); kernel {kern}")
+    assert not torch.equal(y_rest, y_lit)                                  # the other form really ran
+    assert e_rest <= 2e-5 * max(1.0, scale) and e_rest <= 2 * max(e_lit, 2e-6 * max(1.0, scale))
+    assert float((sr - sl).abs().max()) <= 1e-5 * max(1.0, float(sl.abs().max())) and float((qr - ql).abs().max()) <= 1e-5 * max(1.0, float(ql.abs().max()))
+    # off: the flag routes back to the literal form bit for bit
+    y_off, _ = conv.run(s0, s1, rest0=rest.to(DEV), arith=AR.DEFAULT.replace(affine_in_weights=False))
+    assert torch.equal(y_off, y_lit)
+
+
 # ------------------------------------------------------------------------------------------------ polyphase decoder convolutions
 @pytest.mark.parametrize("C0,C1,Cout,dims,B", [(32, 64, 32, (16, 16, 16), 1), (64, 128, 64, (8, 16, 8), 2), (128, 256, 128, (8, 8, 8), 1),
                                                (32, 64, 32, (64, 64, 64), 2), (16, 32, 64, (4, 6, 10), 1)])
