@@ -59,6 +59,8 @@ PROTOTYPES = {
     "gn_gather_nn": [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _vp, _vp],
     "gn_gather_nn_batch": [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _f64, _vp, _vp],
     "gn_mesh_compact_workspace_bytes": [_i64, _i64],
+    "gn_mesh_largest_component_workspace_bytes": [_i64],
+    "gn_mesh_largest_component": [_vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp],
     "gn_mesh_compact": [_vp, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp],
     "gn_scale_verts": [_vp, _i64, _f64, _vp, _vp],
     "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
@@ -66,7 +68,7 @@ PROTOTYPES = {
     "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
-_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz}
+_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz, "gn_mesh_largest_component_workspace_bytes": _sz}
 
 _lib = None
 

@@ -158,3 +158,26 @@ def delete_invalid_verts(mc_verts, mc_faces, is_vert_on_surface):
     remap = torch.zeros(mc_verts.shape[0], dtype=torch.long, device=mc_verts.device)
     remap[used] = torch.arange(used.numel(), device=mc_verts.device)
     return mc_verts[used], remap[faces]
+
+
+def largest_connected_component(mc_faces, num_verts):
+    """eval.py:497-503 / :536-540 (igl.adjacency_matrix + igl.connected_components + np.argmax(cc_sizes)): -> is_cc_vert, a bool mask over the
+    vertices.  Device kernel (csrc/mesh_cc.hip gn_mesh_largest_component); host tensors are taken to the current GPU and the mask comes back
+    to where the faces live."""
+    if mc_faces.is_cuda:
+        return ops.mesh_largest_component(mc_faces, num_verts)[0]
+    mask, _ = ops.mesh_largest_component(mc_faces.cuda(), num_verts)
+    return mask.to(mc_faces.device)
+
+
+def remove_holes(mc_verts, mc_faces, pred_value, value_threshold, extra_verts=()):
+    """the reference's hole removal, eval.py:529-548: vertices whose predicted on-surface value exceeds the threshold, the faces made of them
+    only (delete_invalid_verts), then the largest connected component of what is left (delete_invalid_verts again).  extra_verts: further
+    per-vertex arrays carried through both compactions (eval.py's pred_mc_sim_verts).  -> (verts, faces, [extras...]) of the component."""
+    on_surface = pred_value > value_threshold
+    v1, f1 = delete_invalid_verts(mc_verts, mc_faces, on_surface)
+    e1 = [delete_invalid_verts(e, mc_faces, on_surface)[0] for e in extra_verts]
+    is_cc = largest_connected_component(f1, v1.shape[0])
+    v2, f2 = delete_invalid_verts(v1, f1, is_cc)
+    e2 = [delete_invalid_verts(e, f1, is_cc)[0] for e in e1]
+    return (v2, f2, *e2)

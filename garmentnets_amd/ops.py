@@ -800,6 +800,35 @@ def mesh_compact(verts, faces, on_surface):
     return out_v[:nv], out_f[:nf]
 
 
+def mesh_largest_component(faces, num_verts, with_labels=False):
+    """eval.py:497-503: -> (is_cc_vert bool [V], info dict) -- the vertices of the largest connected component of the mesh (ties: the
+    component holding the lowest vertex index, as np.argmax over libigl's numbering); info: num_components, size, label [, labels]."""
+    if faces.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"faces: expected an integer tensor, got {faces.dtype}")
+    V, F = int(num_verts), faces.shape[0]
+    if V >= 2 ** 31:
+        raise ValueError("mesh_largest_component: more than 2^31 vertices")
+    if F == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")          # what np.argmax(cc_sizes) says for a mesh without faces
+    if faces.dtype == torch.int64:
+        faces = faces.clamp(min=-1, max=2 ** 31 - 1)
+    faces = _chk(faces.to(torch.int32).contiguous(), torch.int32, "faces")
+    dev = faces.device
+    nbytes = _lib.load().gn_mesh_largest_component_workspace_bytes(V)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+    mask = torch.empty(V, dtype=torch.uint8, device=dev)
+    label = torch.empty(V, dtype=_i32, device=dev) if with_labels else None
+    info = torch.empty(4, dtype=torch.int64, device=dev)
+    _lib.call("gn_mesh_largest_component", _p(faces), F, V, _p(ws), nbytes, _p(mask), _p(label), _p(info), _stream())
+    ncomp, size, lab, bad = [int(c) for c in info.cpu()]
+    if bad:
+        raise IndexError(f"connected components: a face index is out of bounds for {V} vertices")
+    out = dict(num_components=ncomp, size=size, label=lab)
+    if with_labels:
+        out["labels"] = label
+    return mask.bool(), out
+
+
 # ------------------------------------------------------------------------------------------------ evaluation helpers
 def nearest_neighbor(query, ref):
     """-> (idx int32 [Nq], d2 float32 [Nq]) exact 1-NN of every query point in `ref`"""

@@ -323,6 +323,16 @@ size_t gn_mesh_compact_workspace_bytes(int64_t V, int64_t F);
 int gn_mesh_compact(const void *verts, int vert_bytes, const int32_t *faces, const unsigned char *on_surface, int64_t V, int64_t F,
                     void *ws, size_t ws_bytes, void *out_verts, int32_t *out_faces, int64_t *counts, void *stream);
 
+/* Largest connected component of a triangle mesh = the filter of the reference's hole removal (eval.py:497-503, :536-545:
+ * igl.adjacency_matrix + igl.connected_components + np.argmax(cc_sizes), followed by delete_invalid_verts = gn_mesh_compact).  Lock-free
+ * union-find over the mesh edges that always hooks the larger root under the smaller: a component's label is its LOWEST vertex index whatever
+ * the interleaving (libigl numbers components in that order), and of several largest components the one with the lowest label wins (np.argmax
+ * takes the first maximum).  faces [F][3] int32; mask [V] bytes (1 = vertex in the winning component); label [V] int32 or NULL; info = device
+ * int64[4]: number of components, size of the winner, its label (-1 for V = 0), 1 if a face index was outside [0, V). */
+size_t gn_mesh_largest_component_workspace_bytes(int64_t V);
+int gn_mesh_largest_component(const int32_t *faces, int64_t F, int64_t V, void *ws, size_t ws_bytes, unsigned char *mask, int32_t *label,
+                              int64_t *info, void *stream);
+
 /* The decoder MLP of gn_implicit_decode for the shipped shape [128, 256, 256, OUT<=4] on the 16-bit matrix cores: fp32 operands
  * split into two fp16 planes (3 MFMA products per fp32 product, fp32 accumulation -- the f16x2 arithmetic of
  * gn_conv3d_gcr_split), activations chained through registers, weights streamed through an LDS ring

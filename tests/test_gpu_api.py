@@ -86,6 +86,62 @@ def test_mesh_compact_kernel(V, F):
     assert np.array_equal(v32.cpu().numpy(), verts.float().numpy()[used]) and torch.equal(f32, f)
 
 
+@pytest.mark.parametrize("V,F,seed", [(7, 2, 0), (1000, 700, 1), (20000, 9000, 2), (300000, 250000, 3), (64, 640, 4)])
+def test_mesh_largest_component_kernel(V, F, seed):
+    """gn_mesh_largest_component against the oracle's restatement of igl.connected_components + np.argmax (eval.py:497-503): random triangle
+    soups with many components (isolated vertices, ties between largest components), labels = lowest vertex of the component, run-to-run
+    identical whatever the interleaving of the lock-free unions"""
+    from oracle import mesh as OM
+    rng = np.random.default_rng(seed)
+    faces = rng.integers(0, V, size=(F, 3)).astype(np.int32)
+    if seed == 0:
+        faces = np.array([[2, 3, 4], [5, 0, 6]], dtype=np.int32)               # a tie: the component holding vertex 0 wins
+    num, idx, sizes = OM.connected_components(faces, V)
+    want = idx == np.argmax(sizes)
+    first = np.full(num, V, dtype=np.int64)
+    np.minimum.at(first, idx, np.arange(V))
+    ft = torch.from_numpy(faces).to(DEV)
+    mask, info = ops.mesh_largest_component(ft, V, with_labels=True)
+    assert mask.dtype == torch.bool and np.array_equal(mask.cpu().numpy(), want)
+    assert info["num_components"] == num and info["size"] == int(sizes.max()) and info["label"] == int(first[np.argmax(sizes)])
+    assert np.array_equal(info["labels"].cpu().numpy().astype(np.int64), first[idx])
+    for _ in range(3):                                                          # deterministic
+        m2, i2 = ops.mesh_largest_component(ft.long(), V, with_labels=True)
+        assert torch.equal(m2, mask) and torch.equal(i2["labels"], info["labels"])
+    print(f"V={V} F={F}: {num} components, largest {int(sizes.max())}")
+
+
+def test_mesh_largest_component_errors_and_hole_removal_on_a_real_mesh():
+    """error contract (no faces: np.argmax of an empty sequence -> ValueError; a face index out of range -> IndexError as numpy) and the
+    reference's whole hole removal (eval.py:529-548: threshold -> delete_invalid_verts -> largest component -> delete_invalid_verts) on a
+    marching-cubes mesh with several pieces, device tensors against the oracle's numpy restatement"""
+    from oracle import mesh as OM
+    from garmentnets_amd.common.marching_cubes_util import marching_cubes, remove_holes, largest_connected_component
+    with pytest.raises(ValueError):
+        ops.mesh_largest_component(torch.zeros((0, 3), dtype=torch.int32, device=DEV), 5)
+    with pytest.raises(IndexError):
+        ops.mesh_largest_component(torch.tensor([[0, 1, 9]], dtype=torch.int32, device=DEV), 5)
+    # three blobs of different size in a 48^3 volume
+    z, y, x = np.meshgrid(*([np.arange(48, dtype=np.float32)] * 3), indexing="ij")
+    vol = np.zeros((48, 48, 48), dtype=np.float32)
+    for c, r in (((12, 12, 12), 7.5), ((32, 30, 28), 11.3), ((10, 38, 36), 5.2)):
+        vol = np.maximum(vol, 1.0 - np.sqrt((z - c[0]) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2) / r)
+    verts, faces, _, values, _ = marching_cubes(torch.from_numpy(vol).to(DEV), 0.3)
+    vn, fn = verts.cpu().numpy(), faces.cpu().numpy()
+    assert OM.connected_components(fn, len(vn))[0] == 3
+    is_cc = largest_connected_component(faces, verts.shape[0])
+    assert np.array_equal(is_cc.cpu().numpy(), OM.largest_component_mask(fn, len(vn)))
+    assert np.array_equal(largest_connected_component(faces.cpu(), verts.shape[0]).numpy(), is_cc.cpu().numpy()) and not largest_connected_component(faces.cpu(), 5 + verts.shape[0]).is_cuda
+    # hole head stand-in: a per-vertex value that cuts a band out of the big blob (splitting it) and all of the smallest one
+    pv = torch.from_numpy(((np.abs(vn[:, 0] - 32.0) > 2.0) & (vn[:, 1] < 34.0)).astype(np.float32)).to(DEV)
+    extra = verts * 2.0 + 1.0
+    v2, f2, e2 = remove_holes(verts, faces, pv, 0.5, extra_verts=(extra,))
+    rv, rf = OM.remove_holes(vn, fn, pv.cpu().numpy(), 0.5)
+    assert np.array_equal(v2.cpu().numpy(), rv) and np.array_equal(f2.cpu().numpy(), rf) and np.array_equal(e2.cpu().numpy(), rv * 2.0 + 1.0)
+    assert 0 < len(rv) < len(vn) and OM.connected_components(rf, len(rv))[0] == 1
+    print(f"hole removal: {len(vn)} -> {len(rv)} vertices, {len(fn)} -> {len(rf)} faces")
+
+
 def test_forward_with_explicit_query_sets_against_oracle():
     """ConvImplicitWNFPipeline.forward(data) (networks/conv_implicit_wnf.py:314-338): data.volume_query_points / surf_query_points
     (B,M,3) -> volume_decoder_result / surface_decoder_result, the reference's result-dict layout, values vs the oracle decoders"""
