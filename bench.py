@@ -24,6 +24,8 @@ timings (RCCL).  Rank 0 prints ONE JSON line:
   occupancy_aware       the same K steps with the library's default occupancy-aware first two UNet convolutions (exact: bit-identical outputs,
                         tests/test_gpu_parity.py::test_sparse_first_conv_is_bit_identical_to_dense).  The HEADLINE value is measured with
                         that path switched OFF: every tile goes through the matrix cores and the number does not depend on where the points fall
+  literal_affine        the same K steps with Arith.affine_in_weights off (the GroupNorm shift inside the MFMA operand of the first two encoder
+                        convolutions): the same-box A/B of the power lever of DESIGN.md 4.3
   hbm_members           the HBM-bound members of the path (zero-fill, scatter, max-pool, lattice sampler, GGM, MC33 stages): HIP-event time,
                         algorithmic bytes, fraction of 8 TB/s
   validation            untimed: a batch of IDENTICAL garments (PointConv self-loop quirk off) must give the same WNF and mesh in the
@@ -600,6 +602,11 @@ def main():
             vin = model.volume_agg(model.pointnet2_forward(data)["nocs_data"])
             probe["occ0"] = (vin[0] != 0).any(dim=0).cpu()
             del vin
+    literal = None          # the same steps with the GroupNorm shift inside the MFMA operand (Arith.affine_in_weights off): the A/B of DESIGN.md 4.3 on THIS box
+    if not args.no_occupancy_pass and args.workload == "full" and args.conv_mode == "f16x2" and headline.affine_in_weights:
+        model.arith = headline.replace(affine_in_weights=False)
+        literal, _, _ = timed(step, args.steps, 1)
+        model.arith = headline
 
     # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods.  The same
     # step carries the HIP-event brackets of the HBM-bound members (hbm_members)
@@ -662,7 +669,7 @@ def main():
     # the only collective: per-rank (garments, seconds of each timed pass) over RCCL/xGMI
     n_local = (hi - lo) * args.steps
     per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0, occupancy["seconds"] if occupancy else 0.0,
-                                        in_flight or 0.0], device=metrics_dev)
+                                        in_flight or 0.0, literal or 0.0], device=metrics_dev)
     all_sums = parallel.gather_vector(checksums, device=metrics_dev)
     if rank == 0:
         value, tmax = parallel.aggregate_throughput(per_rank)
@@ -697,7 +704,9 @@ def main():
                        "points": args.points, "grid": args.grid, "reduce": args.reduce,
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level[0] else 0.5,
                        "weights": "seeded synthetic (reference architecture)" + (" + planted NOCS path" if args.input == "planted" else ""),
-                       "encoder_convs": "dense (occupancy-aware launch OFF for the headline)", "mesh_verts_per_step": verts_total,
+                       "encoder_convs": "dense: every tile through the matrix cores (occupancy-aware launch OFF for the headline)" + (
+                           "; GroupNorm affine of the two convolutions behind the scattered volume folded into per-sample weights + a bias table, operand exactly zero in "
+                           "empty cells (Arith.affine_in_weights; the literal form is timed as literal_affine)" if headline.affine_in_weights and args.conv_mode == "f16x2" else ""), "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
             "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh); K batches "
                             "begun and finished between the two barriers" + (
@@ -736,6 +745,13 @@ def main():
                 "what": "the library default: the first two UNet convolutions visit only the output tiles that can see an occupied cell (exact, bit-identical "
                         "to the dense launch; switched off for the headline value) -- same input, same K steps",
                 "occupied_cells_per_garment": occupancy["occupied_cells_per_garment"], "active_tile_fraction": occupancy["active_tile_fraction"]}
+        if literal:
+            tl = max(r[6] for r in per_rank)
+            line["literal_affine"] = {
+                "value": garments / tl, "unit": "garments/s", "ms_per_step": 1e3 * tl / args.steps,
+                "what": "the same K steps with Arith.affine_in_weights off: the GroupNorm shift inside the MFMA operand of the first two encoder convolutions "
+                        "(every voxel of the >= 99.7 % empty volume non-zero) instead of in per-sample weights + a bias table -- the same MACs through the same "
+                        "kernels; the difference is clock under the socket's power cap (DESIGN.md 4.3)"}
         if validation is not None:
             line["validation"] = validation
         if world == 1 and not args.no_cpu_baseline:
