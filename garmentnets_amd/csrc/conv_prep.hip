@@ -137,6 +137,7 @@ extern "C" int gn_conv_affine_pack(const float *w, int Cin, int Cout, const floa
     GN_REQUIRE(pack_bytes >= gn_conv_affine_pack_bytes(B, Cin, Cout), "gn_conv_affine_pack: pack buffer too small");
     const size_t need = (size_t)B * Cin * (4 + 8) + (size_t)B * Cout * 4;
     GN_REQUIRE(ws_bytes >= need, "gn_conv_affine_pack: workspace too small (%zu < %zu)", ws_bytes, need);
+    GN_REQUIRE(((uintptr_t)ws & 7) == 0 && ((uintptr_t)pack & 15) == 0, "gn_conv_affine_pack: ws must be 8-byte aligned, pack 16-byte aligned");
     hipStream_t st = gn_stream(stream);
     double *mconst = (double *)ws;                                          // [B][Cin] (8-byte aligned first)
     float *wfac = (float *)(mconst + (size_t)B * Cin);                      // [B][Cin]
