@@ -81,11 +81,8 @@ class SingleConv(PackedModule, nn.Sequential):
                 small_in = sparse.get("small_in")
                 if small_in is None:
                     small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-                every = torch.ones((B, 2), dtype=torch.uint8, device=src0.device)          # the 5^3 volume is two 4 x 8 x 8 tiles: all active
                 ncls = (2 * reach + 1) ** 3
-                dummy = torch.zeros((B, ncls, cout), dtype=torch.float32, device=src0.device)
-                small_out = ops.conv3d_gcr_split(small_in, None, a, d, cache[key], cout, relu=True, act_inv=act_inv, tile_active=every, kconst=dummy,
-                                                 kreach=reach)
+                small_out = ops.conv3d_gcr_split(small_in, None, a, d, cache[key], cout, relu=True, act_inv=act_inv)      # (a plain dense launch)
                 # class -> voxel of the 5^3 volume: reach 1 = voxels 0 / 2 / 4 per axis, reach 2 = all five (strided views: nothing is
                 # copied from the host, so the path can be captured into a HIP graph)
                 step = 2 if reach == 1 else 1
@@ -141,10 +138,8 @@ class SingleConv(PackedModule, nn.Sequential):
                 and (reach == 1 or small_in is not None)):
             if small_in is None:
                 small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-            every = torch.ones((B, 2), dtype=torch.uint8, device=src0.device)
             ncls = (2 * reach + 1) ** 3
-            dummy = torch.zeros((B, ncls, cout), dtype=torch.float32, device=src0.device)
-            small_out = ops.conv3d_gcr_split_persample(small_in, prep, relu=True, tile_active=every, kconst=dummy, kreach=reach)
+            small_out = ops.conv3d_gcr_split_persample(small_in, prep, relu=True)                                         # (a plain dense launch)
             step = 2 if reach == 1 else 1
             kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
             sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)

@@ -52,10 +52,12 @@ struct SplitArgs {
     int tiles_y, tiles_x;
     const float *out_scale;   // [Cout] exact powers of two undoing the pack's per-output-channel weight scales (1 for the bf16 modes)
     const float *act_inv;     // NULL or [B]: exact power of two undoing the sample's activation scale (gn_groupnorm_affine)
-    // occupancy-aware launch (the first UNet layer, whose input is a scattered volume): tile_active[b][tile] == 0 -> the tile's halo
-    // holds no occupied cell, every output is one of 27 per-sample border-class constants kconst[b][class][Cout] (class =
-    // (cz * 3 + cy) * 3 + cx, c = 0 / 1 / 2 for first voxel / interior / last voxel of the axis): stored without touching the matrix cores
-    const unsigned char *tile_active;
+    // occupancy-aware launch (the layers behind a scattered volume): only the tiles listed in active_list -- entries b * tiles_per_sample + tile at
+    // the kernel's tile granularity, ascending, *active_count of them (device values: occ_compact_kernel) -- are visited by this kernel; the grid is the
+    // dense launch's, workgroups past the list's end return at once.  Every other tile holds nothing but border-class constants and is written by
+    // conv_fill_inactive_kernel (kconst[b][class][Cout], class = (cz * n + cy) * n + cx with n = 2 kreach + 1, c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r)).
+    const int *active_list;
+    const int *active_count;
     const float *kconst;
     // polyphase form of a layer whose second source is nearest-upsampled (the decoders' first convolutions): the upsampled part is a
     // 2x2x2-tap convolution per output parity class on the COARSE volume (8/27 of the MACs), computed by gn_upconv_partial (upconv.hip);
@@ -73,6 +75,33 @@ struct SplitArgs {
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
 };
+
+// Work item of this workgroup: sample b, tile (index inside the sample at the kernel's tile granularity), column block cb.
+// XCD-aware order (workgroup i runs on XCD i % 8, each XCD has its own L2): every XCD walks a CONTIGUOUS range of (tile, column block) pairs,
+// column blocks of one tile adjacent, tiles in z-fastest order -> the halo overlap of neighbouring tiles and the other column blocks' re-read of
+// the same input hit that XCD's L2.  Bijective for any size.  Dense launch: per sample (blockIdx.y) over gridDim.x items.  Compacted launch
+// (active_list): over the *active_count * ncb items of the whole batch, linear workgroup id across the grid; -> false: nothing to do.
+__device__ __forceinline__ bool sp_work_item(const SplitArgs &p, int ncb, int tiles_per_sample, int &b, int &tile, int &cb) {
+    unsigned nblk = gridDim.x, lin = blockIdx.x;
+    if (p.active_list) {
+        nblk = (unsigned)(*p.active_count) * (unsigned)ncb;
+        lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= nblk) return false;
+    }
+    const unsigned xcd = lin & 7u, jx = lin >> 3, qx = nblk >> 3, rx = nblk & 7u;
+    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
+    const unsigned t = logical / (unsigned)ncb;
+    cb = (int)(logical % (unsigned)ncb);
+    if (p.active_list) {
+        const int item = p.active_list[t];
+        b = item / tiles_per_sample;
+        tile = item - b * tiles_per_sample;
+    } else {
+        b = blockIdx.y;
+        tile = (int)t;
+    }
+    return true;
+}
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
@@ -193,23 +222,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = p.C0 + p.C1;
-    // XCD-aware work-item order (workgroup b runs on XCD b % 8, each XCD has its own L2): every XCD walks a CONTIGUOUS
-    // range of (tile, column block) pairs, column blocks of one tile adjacent, tiles in z-fastest order -> the halo overlap of
-    // neighbouring tiles and the second column block's re-read of the same input hit that XCD's L2.  Bijective for any size.
-    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
-    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
     const int ncb = p.Cout / CT;
-    int tile = (int)(logical / (unsigned)ncb);
-    const int cb = (int)(logical % (unsigned)ncb);
     const int tiles_z = (p.D + TZ - 1) / TZ;
+    int b, tile, cb;
+    if (!sp_work_item(p, ncb, tiles_z * p.tiles_x * p.tiles_y, b, tile, cb)) return;      // (workgroup-uniform)
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
     const int z0 = tz * TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
     const int n0 = cb * CT;
-    const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
-    const bool inactive = p.tile_active && !p.tile_active[(int64_t)b * (tiles_z * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tiles_z + tz];
 
     f32x16s acc[NF][NT], tot[NF][NT];               // fragment f = 2 m + t: z-slice wave + 4 m, y half t
 #pragma unroll
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
-    if (!inactive) {                                // (workgroup-uniform: an inactive tile issues no DMA, no staging, no MFMA)
+    {
     const int abase = HL::at(wave, r >> 3, r & 7) + 16 * h;                          // bytes; plane pl at +32*pl
     constexpr int AF1 = 4 * HL::ROWP, AFZ = 4 * SP_HY * HL::ROWP;                       // y half, second z-slice
     const int nslices = Cin / SP_KS;
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
     double ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
-    const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
+    const bool full = z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
     const bool interior = z0 > 0 && z0 + TZ < p.D && y0 > 0 && y0 + SP_TY < p.H && x0 > 0 && x0 + SP_TX < p.W;   // no voxel of the tile on a face
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -442,16 +464,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_kernel(SplitArgs p) {
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v;
-                    if (inactive) {                  // the finished value a dense launch gives a voxel of this border class
-                        const int nc = 2 * p.kreach + 1;
-                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
-                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
-                    } else {
-                        v = __fmul_rn(tot[f][u][q], osc);
-                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
-                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
-                        if (p.relu) v = gn_relu(v);
-                    }
+                    v = __fmul_rn(tot[f][u][q], osc);
+                    if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
+                    if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += (double)v;
                     ssq[u] += (double)v * (double)v;
@@ -508,24 +524,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int zw = 4 * (wave & 1), xw = NX * (wave >> 1);
     const int Cin = p.C0;
-    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
-    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
     const int ncb = p.Cout / 32;
-    int tile = (int)(logical / (unsigned)ncb);
-    const int cb = (int)(logical % (unsigned)ncb);
     const int tiles_z = (p.D + T - 1) / T;
+    int b, tile, cb;
+    if (!sp_work_item(p, ncb, tiles_z * p.tiles_x * p.tiles_y, b, tile, cb)) return;      // (workgroup-uniform)
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
     const int z0 = tz * T, y0 = ty * T, x0 = tx * T;
     const int n0 = cb * 32;
-    const int b = blockIdx.y;
-    bool inactive = false;
-    if (p.tile_active) {                             // flags are per 4 x 8 x 8 tile (gn_grid_tile_flags): this block is two of them
-        const int tz4 = (p.D + SP_TZ - 1) / SP_TZ;
-        const unsigned char *fl = p.tile_active + (int64_t)b * (tz4 * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tz4 + 2 * tz;
-        inactive = !fl[0] && !(2 * tz + 1 < tz4 && fl[1]);
-    }
 
     f32x16s acc[NX], tot[NX];
 #pragma unroll
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; tot[t][q] = 0.f; }
 
-    if (!inactive) {                                // (workgroup-uniform)
+    {
     const int nslices = Cin / SP_KS, ngroups = nslices * 9;
     const int64_t bstep = (int64_t)ncb * P * 1024;                                    // bytes per (slice, tap) step of the pack
     // piece k of a group = tap 3g + (k >> 1), plane k & 1; wave w fetches pieces w and w + 4 (waves 0, 1 only)
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
     const int n = n0 + r;
     const float osn = p.out_scale[(int64_t)b * p.osc_bstride + n];
             const float osc = p.act_inv ? __fmul_rn(osn, p.act_inv[b]) : osn;
-    const bool full = !inactive && z0 + T <= p.D && y0 + T <= p.H && x0 + T <= p.W;       // (workgroup-uniform)
+    const bool full = z0 + T <= p.D && y0 + T <= p.H && x0 + T <= p.W;       // (workgroup-uniform)
     const bool interior = z0 > 0 && z0 + T < p.D && y0 > 0 && y0 + T < p.H && x0 > 0 && x0 + T < p.W;
     const float *kb = p.kbias ? p.kbias + (int64_t)b * 64 * p.Cout + n : nullptr;
     if (full) {
@@ -693,16 +700,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_split_strip_kernel(SplitArgs p)
                 const int gz = z0 + zw + (q >> 2), gy = y0 + 4 * h + (q & 3), gx = x0 + xw + xo;
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v;
-                    if (inactive) {                  // the finished value a dense launch gives a voxel of this border class
-                        const int nc = 2 * p.kreach + 1;
-                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
-                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
-                    } else {
-                        v = __fmul_rn(tot[xo][q], osc);
-                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
-                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
-                        if (p.relu) v = gn_relu(v);
-                    }
+                    v = __fmul_rn(tot[xo][q], osc);
+                    if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
+                    if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum += (double)v;
                     ssq += (double)v * (double)v;
@@ -751,22 +752,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), zs = wave & 3, cg = wave >> 2;
     const int Cin = p.C0 + p.C1;
-    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, qx = nblk >> 3, rx = nblk & 7u;
-    const unsigned logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + jx;
     const int ncb = p.Cout / CW;
-    int tile = (int)(logical / (unsigned)ncb);
-    const int cb = (int)(logical % (unsigned)ncb);
     const int tiles_z = (p.D + TZ - 1) / TZ;
+    int b, tile, cb;
+    if (!sp_work_item(p, ncb, tiles_z * p.tiles_x * p.tiles_y, b, tile, cb)) return;      // (workgroup-uniform)
     const int tz = tile % tiles_z; tile /= tiles_z;
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile;
     const int z0 = tz * TZ, y0 = ty * SP_TY, x0 = tx * SP_TX;
     const int n0 = cb * 128 + cg * 64;
     const int zl = zs;                              // this wave's z-slice inside the tile
-    const int b = blockIdx.y;
     const int D1 = p.D >> 1, H1 = p.H >> 1, W1 = p.W >> 1;
     const int nslices = Cin / SP_KS;
-    const bool inactive = p.tile_active && !p.tile_active[(int64_t)b * (tiles_z * p.tiles_x * p.tiles_y) + ((int64_t)ty * p.tiles_x + tx) * tiles_z + tz];
 
     f32x16s acc[2][NT], tot[2][NT];
 #pragma unroll
@@ -776,7 +773,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
 #pragma unroll
             for (int q = 0; q < 16; ++q) { acc[t][u][q] = 0.f; tot[t][u][q] = 0.f; }
 
-    if (!inactive) {                                // (workgroup-uniform: an inactive tile issues no DMA, no staging, no MFMA)
+    {
     for (int i = tid; i < Cin; i += 512) { adl[i] = p.a[(int64_t)b * Cin + i]; adl[384 + i] = p.d[(int64_t)b * Cin + i]; }
 
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
@@ -950,7 +947,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     double ssum[NT], ssq[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) { ssum[u] = 0.0; ssq[u] = 0.0; }
-    const bool full = !inactive && z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
+    const bool full = z0 + TZ <= p.D && y0 + SP_TY <= p.H && x0 + SP_TX <= p.W;       // (workgroup-uniform)
     const bool interior = z0 > 0 && z0 + TZ < p.D && y0 > 0 && y0 + SP_TY < p.H && x0 > 0 && x0 + SP_TX < p.W;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -973,16 +970,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
                 const int gy = y0 + t * 4 + (i >> 3), gx = x0 + (i & 7);
                 if (gz < p.D && gy < p.H && gx < p.W) {
                     float v;
-                    if (inactive) {                  // the finished value (scale and ReLU applied) a dense launch gives a voxel of this border class
-                        const int nc = 2 * p.kreach + 1;
-                        const int cls = (sp_axis_class(gz, p.D, p.kreach) * nc + sp_axis_class(gy, p.H, p.kreach)) * nc + sp_axis_class(gx, p.W, p.kreach);
-                        v = p.kconst[((int64_t)b * (nc * nc * nc) + cls) * p.Cout + n];
-                    } else {
-                        v = __fmul_rn(tot[t][u][q], osc);
-                        if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
-                        if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
-                        if (p.relu) v = gn_relu(v);
-                    }
+                    v = __fmul_rn(tot[t][u][q], osc);
+                    if (kb) v = __fadd_rn(v, kb[(int64_t)((sp_axis_mask(gz, p.D) * 4 + sp_axis_mask(gy, p.H)) * 4 + sp_axis_mask(gx, p.W)) * p.Cout]);
+                    if (p.partial) v = __fadd_rn(v, p.partial[((((int64_t)b * (p.D >> 1) + (gz >> 1)) * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * (8 * p.Cout) + (((gz & 1) * 4 + (gy & 1) * 2 + (gx & 1)) * p.Cout + n)]);
+                    if (p.relu) v = gn_relu(v);
                     p.out[((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + n] = v;
                     ssum[u] += (double)v;
                     ssq[u] += (double)v * (double)v;
@@ -1008,11 +999,117 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wide_kernel(SplitArgs p) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ occupancy-aware launch: list + fill
+// tile_active holds one flag per 4 x 8 x 8 tile (gn_grid_tile_flags).  The kernels above visit only the ACTIVE tiles, through a compact,
+// ascending list at their own tile granularity (pair = 1: 4 x 8 x 8; pair = 2: the x-strip kernel's 8 x 8 x 8 blocks = two flags along z),
+// built here by ONE workgroup (B * tiles <= a few 10^5 entries: ~20 us; ballot / popcount scan, deterministic order).
+__global__ __launch_bounds__(1024) void occ_compact_kernel(const unsigned char *__restrict__ flags, int B, int tz4, int tyx, int pair,
+                                                           int *__restrict__ list, int *__restrict__ count) {
+    const int Tz = pair == 2 ? (tz4 + 1) / 2 : tz4, Tk = tyx * Tz, total = B * Tk;
+    __shared__ int wsum[16];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        const int i = base + tid;
+        bool act = false;
+        if (i < total) {
+            const int b = i / Tk, t = i - b * Tk, yx = t / Tz, z = t - yx * Tz;
+            const unsigned char *f = flags + ((int64_t)b * tyx + yx) * tz4;
+            act = pair == 2 ? (f[2 * z] != 0 || (2 * z + 1 < tz4 && f[2 * z + 1] != 0)) : f[z] != 0;
+        }
+        const unsigned long long m = __ballot(act);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (act) list[off + before] = i;
+        __syncthreads();
+        if (tid == 0) {
+            int tsum = 0;
+            for (int w = 0; w < 16; ++w) tsum += wsum[w];
+            running += tsum;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = running;
+}
+
+// Every INACTIVE tile: nothing but the finished border-class constants a dense launch would store there (kconst), plus their share of the
+// epilogue statistics.  One 256-thread workgroup per (y, x) COLUMN of tiles and sample: it walks the column's tiles (at the conv kernel's tile
+// granularity), skips the active ones and accumulates the statistics of the rest in registers -- one reduction and one set of atomics per
+// column instead of per tile.  A thread owns one channel quad and every (256 / quads)-th voxel: float4 stores, 512 contiguous bytes per voxel
+// for 128 channels.  Tiles away from the faces hold ONE value per channel: their statistics are count * v (the same fp64 value the voxel-by-
+// voxel sum gives: a thread adds at most 2^6 equal 24- / 48-bit terms).  HBM-bound.
+__global__ __launch_bounds__(256) void conv_fill_inactive_kernel(SplitArgs p, const unsigned char *__restrict__ flags, int pair) {
+    const int TZ = SP_TZ * pair, tz4 = (p.D + SP_TZ - 1) / SP_TZ, tiles_z = (p.D + TZ - 1) / TZ;
+    const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x, b = blockIdx.y;
+    const unsigned char *fl = flags + ((int64_t)b * p.tiles_y * p.tiles_x + (int64_t)ty * p.tiles_x + tx) * tz4;
+    const int y0 = ty * SP_TY, x0 = tx * SP_TX, r = p.kreach, nc = 2 * r + 1;
+    const int quads = p.Cout >> 2, tid = threadIdx.x;                           // Cout <= 1024 (checked by the caller): quads <= 256
+    const int vpp = 256 / quads, quad = tid % quads, vl = tid / quads;          // voxels per pass; this thread's quad / voxel lane
+    const bool yx_inner = y0 >= r && y0 + SP_TY <= p.H - r && x0 >= r && x0 + SP_TX <= p.W - r;
+    const float *kc = p.kconst + (int64_t)b * (nc * nc * nc) * p.Cout + quad * 4;
+    const float4 centre = *reinterpret_cast<const float4 *>(kc + (int64_t)((r * nc + r) * nc + r) * p.Cout);
+    double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+    if (vl < vpp) {
+        for (int tz = 0; tz < tiles_z; ++tz) {
+            if (fl[pair * tz] || (pair == 2 && pair * tz + 1 < tz4 && fl[pair * tz + 1])) continue;      // active: the conv kernel's
+            const int z0 = tz * TZ;
+            const bool uniform = yx_inner && z0 >= r && z0 + TZ <= p.D - r;
+            float *ob = p.out + ((((int64_t)b * p.D + z0) * p.H + y0) * p.W + x0) * p.Cout + quad * 4;
+            if (uniform) {
+                int cnt = 0;
+                for (int v = vl; v < TZ * 64; v += vpp, ++cnt)
+                    *reinterpret_cast<float4 *>(ob + (((int64_t)(v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cout) = centre;
+                const double n = (double)cnt;
+                s4[0] += n * (double)centre.x; s4[1] += n * (double)centre.y; s4[2] += n * (double)centre.z; s4[3] += n * (double)centre.w;
+                q4[0] += n * ((double)centre.x * (double)centre.x); q4[1] += n * ((double)centre.y * (double)centre.y);
+                q4[2] += n * ((double)centre.z * (double)centre.z); q4[3] += n * ((double)centre.w * (double)centre.w);
+                continue;
+            }
+            for (int v = vl; v < TZ * 64; v += vpp) {
+                const int gz = z0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gx = x0 + (v & 7);
+                if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+                const int cls = (sp_axis_class(gz, p.D, r) * nc + sp_axis_class(gy, p.H, r)) * nc + sp_axis_class(gx, p.W, r);
+                const float4 cv = *reinterpret_cast<const float4 *>(kc + (int64_t)cls * p.Cout);
+                *reinterpret_cast<float4 *>(p.out + ((((int64_t)b * p.D + gz) * p.H + gy) * p.W + gx) * p.Cout + quad * 4) = cv;
+                s4[0] += (double)cv.x; s4[1] += (double)cv.y; s4[2] += (double)cv.z; s4[3] += (double)cv.w;
+                q4[0] += (double)cv.x * (double)cv.x; q4[1] += (double)cv.y * (double)cv.y; q4[2] += (double)cv.z * (double)cv.z; q4[3] += (double)cv.w * (double)cv.w;
+            }
+        }
+    }
+    if (!p.osum) return;
+    __shared__ double red[256][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[tid][i] = s4[i]; red[tid][4 + i] = q4[i]; }
+    __syncthreads();
+    if (vl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double a = 0.0, c = 0.0;
+            for (int k = 0; k < vpp; ++k) { a += red[tid + k * quads][i]; c += red[tid + k * quads][4 + i]; }
+            if (a != 0.0 || c != 0.0) {
+                atomicAdd(&p.osum[(int64_t)b * p.Cout + quad * 4 + i], a);
+                atomicAdd(&p.osq[(int64_t)b * p.Cout + quad * 4 + i], c);
+            }
+        }
+    }
+}
+
+extern "C" size_t gn_conv3d_occupancy_workspace_bytes(int B, int D, int H, int W) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return ((size_t)B * gn_cdiv(D, SP_TZ) * gn_cdiv(H, SP_TY) * gn_cdiv(W, SP_TX) + 16) * sizeof(int);
+}
+
 static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                  const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
                                  int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
                                  const float *kconst, int kreach, const float *partial, const float *kbias, int64_t wp_bstride, int osc_bstride,
-                                 void *stream) {
+                                 void *occ_ws, size_t occ_ws_bytes, void *stream) {
     GN_REQUIRE(B >= 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, "gn_conv3d_gcr_split: bad sizes");
     GN_REQUIRE(mode == GN_SPLIT_BF16X2 || mode == GN_SPLIT_BF16X3 || mode == GN_SPLIT_F16X2, "gn_conv3d_gcr_split: mode must be GN_SPLIT_BF16X2, _BF16X3 or _F16X2");
     GN_REQUIRE(out_scale != nullptr, "gn_conv3d_gcr_split: out_scale [Cout] is required (ones for the bf16 modes)");
@@ -1028,7 +1125,7 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
-    p.tile_active = tile_active; p.kconst = kconst; p.kreach = kreach; p.partial = partial;
+    p.active_list = nullptr; p.active_count = nullptr; p.kconst = kconst; p.kreach = kreach; p.partial = partial;
     p.kbias = kbias; p.wp_bstride = wp_bstride; p.osc_bstride = osc_bstride;
     GN_REQUIRE(!partial || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: a polyphase partial needs even dims");
     const int tz = (int)gn_cdiv(D, SP_TZ);
@@ -1059,6 +1156,18 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     // x-strip variant for the column blocks the 64- and 128-wide kernels do not take (two-plane modes, one full-resolution source)
     const int tiles8 = (int)gn_cdiv(D, 8) * p.tiles_y * p.tiles_x;
     const bool strip = mode != GN_SPLIT_BF16X3 && !wide128 && !wide && C1 == 0 && (int64_t)tiles8 * (Cout / 32) * B >= 512;
+    if (tile_active) {
+        // the active tiles as a compact list at the chosen kernel's tile granularity + the inactive tiles' constants (and their statistics)
+        GN_REQUIRE(occ_ws && occ_ws_bytes >= gn_conv3d_occupancy_workspace_bytes(B, D, H, W) && ((uintptr_t)occ_ws & 3) == 0,
+                   "gn_conv3d_gcr_split: the occupancy-aware launch needs gn_conv3d_occupancy_workspace_bytes(B, D, H, W) bytes of workspace");
+        GN_REQUIRE(Cout % 4 == 0 && Cout <= 1024, "gn_conv3d_gcr_split: the occupancy-aware launch needs Cout <= 1024");
+        const int pair = strip ? 2 : 1;
+        int *count = (int *)occ_ws, *list = count + 16;
+        hipLaunchKernelGGL(occ_compact_kernel, dim3(1), dim3(1024), 0, st, tile_active, B, tz, p.tiles_y * p.tiles_x, pair, list, count);
+        hipLaunchKernelGGL(conv_fill_inactive_kernel, dim3(p.tiles_y * p.tiles_x, B), dim3(256), 0, st, p, tile_active, pair);
+        p.active_list = list;
+        p.active_count = count;
+    }
     if (strip) {
         if (mode == GN_SPLIT_F16X2) hipLaunchKernelGGL((conv3d_split_strip_kernel<true>), dim3(tiles8 * (Cout / 32), B), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv3d_split_strip_kernel<false>), dim3(tiles8 * (Cout / 32), B), dim3(256), 0, st, p);
@@ -1079,9 +1188,9 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
 extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                                    const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H,
                                    int W, int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                                   const float *kconst, int kreach, const float *partial, void *stream) {
+                                   const float *kconst, int kreach, const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream) {
     return conv3d_gcr_split_impl(src0, C0, src1, C1, a, d, wp_planes, mode, out_scale, act_inv_scale, B, D, H, W, Cout, relu, out, out_sum, out_sumsq,
-                                 tile_active, kconst, kreach, partial, nullptr, 0, 0, stream);
+                                 tile_active, kconst, kreach, partial, nullptr, 0, 0, occ_ws, occ_ws_bytes, stream);
 }
 
 // The affine-in-weights form: everything gn_conv_affine_pack (conv_prep.hip) prepared for this batch -- the staging affine (s, -c s), the
@@ -1090,10 +1199,10 @@ extern "C" int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1,
 extern "C" int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
                                              const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                                              double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
-                                             const float *partial, void *stream) {
+                                             const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream) {
     GN_REQUIRE(kbias != nullptr && pack != nullptr, "gn_conv3d_gcr_split_persample: pack and kbias are required");
     GN_REQUIRE(Cin > 0 && Cin % SP_KS == 0 && Cout > 0 && Cout % 32 == 0, "gn_conv3d_gcr_split_persample: channel counts must be multiples of 16 (in) / 32 (out)");
     const int64_t per_sample = (int64_t)(Cin / SP_KS) * 27 * (Cout / 32) * 2 * 1024;
     return conv3d_gcr_split_impl(src, Cin, nullptr, 0, stage_a, stage_d, pack, GN_SPLIT_F16X2, out_scale, nullptr, B, D, H, W, Cout, relu, out, out_sum,
-                                 out_sumsq, tile_active, kconst, kreach, partial, kbias, per_sample, Cout, stream);
+                                 out_sumsq, tile_active, kconst, kreach, partial, kbias, per_sample, Cout, occ_ws, occ_ws_bytes, stream);
 }

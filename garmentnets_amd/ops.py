@@ -413,8 +413,9 @@ def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, 
     C1 = 0 if src1 is None else src1.shape[-1]
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src0.device)
     s, q = _stats_buffers(B, cout, src0.device, with_stats)
+    ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src0.device)
     _lib.call("gn_conv3d_gcr_split", _p(src0), C0, _p(src1), C1, _p(a), _p(d), _p(pack.tensor), pack.mode, _p(pack.out_scale), _p(act_inv), B, D, H, W, cout,
-              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _stream())
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _p(ows), ows_bytes, _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
 
 
@@ -458,9 +459,19 @@ def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_acti
     assert C == prep.cin and B == prep.stage_a.shape[0]
     out = torch.empty((B, D, H, W, prep.cout), dtype=torch.float32, device=src.device)
     s, q = _stats_buffers(B, prep.cout, src.device, with_stats)
+    ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src.device)
     _lib.call("gn_conv3d_gcr_split_persample", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), _p(prep.kbias),
-              B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _stream())
+              B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _p(ows), ows_bytes,
+              _stream())
     return (out, (s, q, D * H * W)) if with_stats else out
+
+
+def _occupancy_ws(tile_active, B, D, H, W, device):
+    """workspace of an occupancy-aware conv launch (the compact list of active tiles): (tensor | None, bytes)"""
+    if tile_active is None:
+        return None, 0
+    n = _lib.load().gn_conv3d_occupancy_workspace_bytes(B, D, H, W)
+    return torch.empty((n,), dtype=torch.uint8, device=device), n
 
 
 def _stats_buffers(B, C, device, want):

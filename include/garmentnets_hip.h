@@ -193,14 +193,17 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
  * axis, c = z for z < r, 2r - (D-1-z) for z >= D-r, r otherwise; the FINISHED values a dense launch produces there -- garmentnets_amd
  * takes them from dense launches of the same layers over a 5 x 5 x 5 all-zero volume with the same affines) and are stored without
  * touching the matrix cores.  kreach = 1: the layer fed by the scattered volume; 2: the layer behind it.  The output is bit-identical
- * to the dense launch.  Two-plane modes only; the launch pins the kernel variant (128-wide for Cout % 128 == 0, else the 32-wide one). */
+ * to the dense launch.  Two-plane modes only.  The call builds a compact, ascending list of the active tiles in occ_ws
+ * (gn_conv3d_occupancy_workspace_bytes(B, D, H, W) bytes; required with tile_active), fills the inactive tiles (constants + their share of
+ * out_sum / out_sumsq) with an HBM-bound kernel and runs the convolution kernel over the listed tiles only. */
+size_t gn_conv3d_occupancy_workspace_bytes(int B, int D, int H, int W);
 /* `partial` (NULL, or [B][D/2][H/2][W/2][8][Cout] from gn_upconv_partial): the polyphase form of a layer whose second source is
  * nearest-upsampled -- this launch then covers the full-resolution source alone (src1 NULL) and its epilogue adds
  * partial[b][z>>1][y>>1][x>>1][(z&1)*4 + (y&1)*2 + (x&1)][n] before the ReLU. */
 int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, const float *a, const float *d,
                         const void *wp_planes, int mode, const float *out_scale, const float *act_inv_scale, int B, int D, int H, int W,
                         int Cout, int relu, float *out, double *out_sum, double *out_sumsq, const unsigned char *tile_active,
-                        const float *kconst, int kreach, const float *partial, void *stream);
+                        const float *kconst, int kreach, const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream);
 
 /* The GroupNorm affine folded into PER-SAMPLE weights (csrc/conv_prep.hip) -- for a 'gcr' layer (components/unet3d.py:66-76) whose input
  * is AT REST almost everywhere: the scattered volume of networks/conv_implicit_wnf.py:92-94 (zero outside the occupied cells) and the
@@ -217,7 +220,7 @@ int gn_conv3d_gcr_split(const float *src0, int C0, const float *src1, int C1, co
  *     out_scale [B][Cout]        exact powers of two undoing the row scales
  *     kbias [B][64][Cout]        class = (mz * 4 + my) * 4 + mx, m = (voxel has a previous neighbour on the axis) | (a next one) << 1
  * ws: B * Cin * 12 + B * Cout * 4 bytes.  gn_conv3d_gcr_split_persample runs the layer from them (GN_SPLIT_F16X2 arithmetic, one source;
- * tile_active / kconst / kreach / partial as gn_conv3d_gcr_split). */
+ * tile_active / kconst / kreach / partial / occ_ws as gn_conv3d_gcr_split). */
 size_t gn_conv_affine_pack_bytes(int B, int Cin, int Cout);
 int gn_conv_affine_pack(const float *w, int Cin, int Cout, const float *a, const float *d, const double *sum, const double *sumsq, int64_t V,
                         const float *coff, int B, void *pack, size_t pack_bytes, float *stage_a, float *stage_d, float *out_scale,
@@ -225,7 +228,7 @@ int gn_conv_affine_pack(const float *w, int Cin, int Cout, const float *a, const
 int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_a, const float *stage_d, const void *pack,
                                   const float *out_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                                   double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
-                                  const float *partial, void *stream);
+                                  const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream);
 
 /* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
  * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27

@@ -11,7 +11,7 @@ model = ConvImplicitWNFPipeline(**hp); model.load_state_dict(sd); model = model.
 x, pos, batch = S.synthetic_cloud(16, 6000, 0, colour="position")
 from garmentnets_amd.batch import Batch
 data = Batch(sizes=[6000] * 16, x=x, pos=pos, batch=batch).to(dev)
-model.arith = model.arith.replace(sparse_first_conv=False)
+model.arith = model.arith.replace(sparse_first_conv=(os.environ.get("PER_LAYER_SPARSE", "0") == "1"))
 rec = []
 def wrap(name, fn, desc):
     def f(*a, **k):
