@@ -26,6 +26,8 @@ PROTOTYPES = {
     "gn_segment_max": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_sa_fused_supported": [_i32, _i32, _i32, _i32],
     "gn_sa_fused": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_sa_fused_scoped": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_sa_gather_scoped": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "gn_global_max_pool": [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
     "gn_knn_interpolate": [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_linear": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],

@@ -8,29 +8,50 @@ gn_fps, gn_ball_query, gn_sa_gather + gn_linear + gn_segment_max, gn_global_max_
 ``batch`` arguments may be the reference's int64 batch vector or a ``Segments`` object (same information plus
 host-side sizes, so that no device synchronisation is needed on the hot path).
 """
+import os
+import threading
+
 import numpy as np
 import torch
 
 from .. import ops
 
-
-import os
-
 FUSED_SA = os.environ.get("GARMENTNETS_FUSED_SA", "1") != "0"      # False: the unfused gather -> gn_linear x3 -> segment-max chain
 
-_PTR_CACHE = {}      # (sizes, device) -> device int32 CSR ptr.  Batch shapes repeat from step to step: no per-step host-to-device copy,
-                     # and nothing that a HIP-graph capture of the forward pass could not record (garmentnets_amd/graphs.py)
+class _DeviceTableCache:
+    """key -> small immutable device int32 table, built once from host data.  Batch shapes repeat from step to step: no per-step
+    host-to-device copy, and nothing that a HIP-graph capture of the forward pass could not record (garmentnets_amd/graphs.py).
+    Shared by the host threads of a process behind a lock (entries are never mutated after insertion)."""
+
+    def __init__(self, limit=256):
+        self._lock, self._tables, self._limit = threading.Lock(), {}, limit
+
+    def get(self, key, build):
+        with self._lock:
+            t = self._tables.get(key)
+            if t is None:
+                if len(self._tables) >= self._limit:
+                    self._tables.clear()
+                t = self._tables[key] = build()
+            return t
+
+
+_PTR_CACHE = _DeviceTableCache()          # (sizes, device) -> CSR ptr
+_SELF_SRC_CACHE = _DeviceTableCache()     # (point sizes, centre sizes, device) -> per-example self-loop sources
 
 
 def _csr_ptr(sizes, device):
-    key = (tuple(sizes), str(device))
-    ptr = _PTR_CACHE.get(key)
-    if ptr is None:
-        if len(_PTR_CACHE) >= 256:
-            _PTR_CACHE.clear()
-        ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).to(device)
-        _PTR_CACHE[key] = ptr
-    return ptr
+    return _PTR_CACHE.get((tuple(sizes), str(device)),
+                          lambda: torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32).to(device))
+
+
+def _example_self_src(sizes, centre_sizes, device):
+    """int32 [M]: for centre c = centre_ptr[b] + i of example b, the point ptr[b] + i -- "point i" of the centre's OWN cloud
+    (include/garmentnets_hip.h: gn_sa_fused_scoped)"""
+    def build():
+        starts = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+        return torch.tensor(np.concatenate([s + np.arange(m) for s, m in zip(starts, centre_sizes)] or [np.zeros(0)]), dtype=torch.int32).to(device)
+    return _SELF_SRC_CACHE.get((tuple(sizes), tuple(centre_sizes), str(device)), build)
 
 
 class Segments:
@@ -75,6 +96,9 @@ class PointConv(torch.nn.Module):
         self.local_nn = local_nn
         self.global_nn = global_nn
         self.add_self_loops = add_self_loops
+        # "batch": PyG's literal rule on the batched bipartite graph (centre i <-> point i of the CONCATENATED cloud: a garment's result
+        # depends on its slot); "example": point i of the centre's own cloud, i.e. what a batch of one gives every garment
+        self.self_loop_scope = "batch"
 
 
 class SAModule(torch.nn.Module):
@@ -99,11 +123,14 @@ class SAModule(torch.nn.Module):
         idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total, start)
         nbr, cnt = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
         pack = self._fused_pack() if FUSED_SA else None
+        self_src = None
+        if self.conv.add_self_loops and self.conv.self_loop_scope == "example" and seg.num > 1:
+            self_src = _example_self_src(seg.sizes, out_sizes, pos.device)
         if pack is not None and x is not None and x.shape[1] == pack.cin:
             # one kernel: gather -> edge MLP on the matrix cores -> BatchNorm -> max; no edge tensor in HBM (csrc/sa_fused.hip)
-            out = ops.sa_fused(x, pos, idx, nbr, cnt, pack, self_loops=self.conv.add_self_loops)
+            out = ops.sa_fused(x, pos, idx, nbr, cnt, pack, self_loops=self.conv.add_self_loops, self_src=self_src)
         else:
-            edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops)
+            edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops, self_src=self_src)
             h = self.conv.local_nn(edges)
             out = ops.segment_max(h, slot_src, cseg.total, S)
         self.last_graph = (idx, nbr)

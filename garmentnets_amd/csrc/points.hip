@@ -273,19 +273,20 @@ extern "C" int gn_ball_query(const float *pos, const int32_t *ptr, const int32_t
 // one wave per (centre, slot) row
 __global__ __launch_bounds__(256) void sa_gather_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ pos,
                                                         const int32_t *__restrict__ centre_idx, const int32_t *__restrict__ nbr,
-                                                        int M, int K, int self_loops, float *__restrict__ out, int ldo,
-                                                        int32_t *__restrict__ slot_src) {
+                                                        int M, int K, int self_loops, const int32_t *__restrict__ self_src,
+                                                        float *__restrict__ out, int ldo, int32_t *__restrict__ slot_src) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int S = K + (self_loops ? 1 : 0);
     if (row >= (int64_t)M * S) return;
     const int c = (int)(row / S), sl = (int)(row % S);
+    const int self = self_src ? self_src[c] : c;  // the point that plays "node c" on the source side (NULL: PyG's literal rule)
     int j;
     if (sl < K) {
         j = nbr[(size_t)c * K + sl];
-        if (self_loops && j == c) j = -1;  // remove_self_loops on numeric equality source == target
+        if (self_loops && j == self) j = -1;  // remove_self_loops on numeric equality source == target
     } else {
-        j = c;  // add_self_loops(num_nodes = M): source = point c of the full cloud
+        j = self;  // add_self_loops(num_nodes = M): source = point c of the full cloud
     }
     float *o = out + row * (int64_t)ldo;
     if (lane == 0) slot_src[row] = j;
@@ -301,16 +302,22 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(const float *__restrict_
     }
 }
 
-extern "C" int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
-                            int M, int K, int self_loops, float *out, int ldo, int32_t *slot_src, void *stream) {
+extern "C" int gn_sa_gather_scoped(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                                   int M, int K, int self_loops, const int32_t *self_src, float *out, int ldo, int32_t *slot_src,
+                                   void *stream) {
     GN_REQUIRE(M >= 0 && K > 0 && C >= 0 && ldo >= C + 3, "gn_sa_gather: bad sizes");
     GN_REQUIRE(C == 0 || x != nullptr, "gn_sa_gather: x is NULL with C>0");
     if (M == 0) return GN_OK;
     int64_t rows = (int64_t)M * (K + (self_loops ? 1 : 0));
     hipLaunchKernelGGL(sa_gather_kernel, dim3((unsigned)gn_cdiv(rows, 4)), dim3(256), 0, gn_stream(stream), x, ldx, C, pos,
-                       centre_idx, nbr, M, K, self_loops, out, ldo, slot_src);
+                       centre_idx, nbr, M, K, self_loops, self_src, out, ldo, slot_src);
     GN_LAUNCH_CHECK("gn_sa_gather");
     return GN_OK;
+}
+
+extern "C" int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                            int M, int K, int self_loops, float *out, int ldo, int32_t *slot_src, void *stream) {
+    return gn_sa_gather_scoped(x, ldx, C, pos, centre_idx, nbr, M, K, self_loops, nullptr, out, ldo, slot_src, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ segment max

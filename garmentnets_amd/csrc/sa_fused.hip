@@ -31,6 +31,7 @@ struct SaArgs {
     const int32_t *nbr;                   // [M][K] ball-query table, valid entries first, -1 padded
     const int32_t *cnt;                   // [M] number of valid entries
     int M, K, self_loops;
+    const int32_t *self_src;              // [M] or NULL: the point that plays "node c" for the self-loop rule (NULL: point c of the whole cloud)
     const float4 *w1, *w2, *w3;           // A-fragment packs [N/32][Kblocks][4][64 lanes] x float4 (ops.pack_sa_fused)
     const float *tab;                     // per layer, 32-unit block, lane half: bias[16] | bn scale[16] | bn shift[16], register order
     float *out; int ldo;                  // [M][ldo]
@@ -132,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaArgs p) {
             if (p.cnt[c] <= 32 * half) continue;
             const int slot = 32 * half + r;
             j = slot < p.K ? p.nbr[(size_t)c * p.K + slot] : -1;
-            if (p.self_loops && j == c) j = -1;           // remove_self_loops: numeric equality of source and target index
+            if (p.self_loops && j == (p.self_src ? p.self_src[c] : c)) j = -1;   // remove_self_loops: numeric equality of source and target index
             ci = p.centre_idx[c];
         } else {                                          // add_self_loops(num_nodes = M): source = point c of the full cloud
             const int c = c0 + r;
             const bool ok = r < G && c < p.M;
             cl = r;
-            j = ok ? c : -1;
+            j = ok ? (p.self_src ? p.self_src[c] : c) : -1;
             ci = ok ? p.centre_idx[c] : 0;
         }
         const bool valid = j >= 0;
@@ -241,9 +242,10 @@ extern "C" int gn_sa_fused_supported(int C, int N1, int N2, int N3) {
     return (C == 3 && N1 == 64 && N2 == 64 && N3 == 128) || (C == 128 && N1 == 128 && N2 == 128 && N3 == 256);
 }
 
-extern "C" int gn_sa_fused(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr, const int32_t *cnt,
-                           int M, int K, int self_loops, const float *w1p, const float *w2p, const float *w3p, const float *tab, int N1, int N2,
-                           int N3, float *out, int ldo, void *stream) {
+extern "C" int gn_sa_fused_scoped(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                                  const int32_t *cnt, int M, int K, int self_loops, const int32_t *self_src, const float *w1p,
+                                  const float *w2p, const float *w3p, const float *tab, int N1, int N2, int N3, float *out, int ldo,
+                                  void *stream) {
     GN_REQUIRE(M >= 0 && K > 0 && K <= 64 && ldo >= N3, "gn_sa_fused: bad sizes (the ball-query table holds at most 64 neighbours)");
     GN_REQUIRE(gn_sa_fused_supported(C, N1, N2, N3), "gn_sa_fused: edge MLP [%d+3,%d,%d,%d] is not instantiated (shipped: [6,64,64,128], [131,128,128,256]); use gn_sa_gather + gn_linear + gn_segment_max", C, N1, N2, N3);
     GN_REQUIRE(C == 0 || (x && ldx >= C && (C < 8 || ldx % 4 == 0)), "gn_sa_fused: feature rows need a 16-byte aligned leading dimension");
@@ -251,10 +253,17 @@ extern "C" int gn_sa_fused(const float *x, int ldx, int C, const float *pos, con
     GN_REQUIRE(pos && centre_idx && nbr && cnt && w1p && w2p && w3p && tab && out, "gn_sa_fused: null pointer");
     SaArgs p;
     p.x = x; p.ldx = ldx; p.pos = pos; p.centre_idx = centre_idx; p.nbr = nbr; p.cnt = cnt; p.M = M; p.K = K; p.self_loops = self_loops;
+    p.self_src = self_src;
     p.w1 = (const float4 *)w1p; p.w2 = (const float4 *)w2p; p.w3 = (const float4 *)w3p; p.tab = tab; p.out = out; p.ldo = ldo;
     hipStream_t st = gn_stream(stream);
     if (C == 3) sa_launch<3, 64, 64, 128>(p, st);
     else sa_launch<128, 128, 128, 256>(p, st);
     GN_LAUNCH_CHECK("gn_sa_fused");
     return GN_OK;
+}
+
+extern "C" int gn_sa_fused(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr, const int32_t *cnt,
+                           int M, int K, int self_loops, const float *w1p, const float *w2p, const float *w3p, const float *tab, int N1, int N2,
+                           int N3, float *out, int ldo, void *stream) {
+    return gn_sa_fused_scoped(x, ldx, C, pos, centre_idx, nbr, cnt, M, K, self_loops, nullptr, w1p, w2p, w3p, tab, N1, N2, N3, out, ldo, stream);
 }

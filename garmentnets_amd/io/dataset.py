@@ -1,11 +1,19 @@
-"""Input side of the hot path: garment sample -> view / point sub-sampling -> noise / z-rotation
-augmentation -> Batch, as ConvImplicitWNFDataset does for inference (/root/reference/datasets/conv_implicit_wnf_dataset.py:
-data_io 134-181, get_base_data 183-229, rotation_augumentation 370-406, noise_augumentation 408-423, __getitem__ 431-461).
+"""Input side of the hot path: one garment sample of the dataset store -> the point cloud the network sees.
 
-Random streams are the reference's: np.random.RandomState(seed = idx when static_epoch_seed else None), drawn in the same order
-(view choice, point choice; one fresh stream per augmentation), so a given (idx, static_epoch_seed=True) yields the same points.
-Volume / surface / marching-cubes-surface query sampling (training targets) is not on the inference path and is not here.
-Reads the dataset's Zarr v2 layout through garmentnets_amd.io.zarr_store (uncompressed or zlib chunks; Blosc needs numcodecs).
+What the reference's ConvImplicitWNFDataset does for inference (/root/reference/datasets/conv_implicit_wnf_dataset.py: data_io
+134-181, get_base_data 183-229, rotation_augumentation 370-406, noise_augumentation 408-423, __getitem__ 431-461) and what its
+data module does to pick the samples of a subset (prepare_data 478-529), re-built around three pieces of this module's own:
+
+  SeededDraws        the random contract in one place.  Every stage (point selection, noise, rotation) draws from a FRESH
+                     numpy RandomState seeded with the sample's dataset index when ``static_epoch_seed`` (None = OS entropy
+                     otherwise), in a fixed order: [views kept] -> [points kept]; [noise]; [angle].  Bit-identical samples
+                     for a given (idx, static_epoch_seed=True) are pinned by tests/golden/ref_dataset.npz.
+  visible_points     view sub-sampling as index arithmetic (np.repeat owner table + np.isin), no per-view loop.
+  FIELD tables       which stored arrays feed which output fields, and which fields a rotation touches, as data.
+
+Training-only targets (volume / surface / marching-cubes-surface query sampling) are not on the inference path and are not here.
+Stores are read through garmentnets_amd.io.zarr_store (Zarr v2; uncompressed / zlib natively, anything else through numcodecs
+when that package is importable).
 """
 import numpy as np
 import torch
@@ -14,115 +22,174 @@ from scipy.spatial.transform import Rotation
 from ..batch import Batch
 from . import zarr_store
 
+# stored array (group, name) -> key of the raw sample dict
+RAW_ARRAYS = {
+    "cloth_sim_verts": ("mesh", "cloth_verts"),
+    "cloth_nocs_verts": ("mesh", "cloth_nocs_verts"),
+    "cloth_faces_tri": ("mesh", "cloth_faces_tri"),
+    "pc_nocs": ("point_cloud", "nocs"),
+    "pc_sim": ("point_cloud", "point"),
+    "pc_sim_rgb": ("point_cloud", "rgb"),
+    "pc_sizes": ("point_cloud", "sizes"),
+}
+RAW_ATTRS = ("scale", "grip_vertex_idx")
+# per-point output field <- (raw array, divisor applied after the float32 cast)
+POINT_FIELDS = {"x": ("pc_sim_rgb", 255), "y": ("pc_nocs", None), "pos": ("pc_sim", None)}
+# fields a z-rotation acts on: simulation-space points always; in task space the query points turn about the NOCS cube's axis instead
+SIM_SPACE_FIELDS = ("pos", "sim_grip_point", "gt_sim_points")
+TASK_SPACE_SIM_FIELDS = ("pos", "sim_grip_point")
+TASK_SPACE_QUERY_FIELDS = ("volume_query_points", "surf_query_points")
+TASK_SPACE_PIVOT = np.array([0.5, 0.5, 0.0], dtype=np.float32)
+SUBSETS = ("train", "val", "test")
+
+
+class SeededDraws:
+    """the per-sample random streams; one fresh RandomState per stage, as the reference seeds them"""
+
+    def __init__(self, idx, static_epoch_seed):
+        self.seed = int(idx) if static_epoch_seed else None
+
+    def fresh(self):
+        return np.random.RandomState(seed=self.seed)
+
+    def point_selection(self, view_sizes, num_views, num_points, num_stored=None):
+        """-> indices (into the stored cloud) of the points kept: `num_views` of the views (only drawn when there are more), then
+        `num_points` of their points without replacement.  RandomState.choice(array, n, replace=False) IS array[permutation(len)[:n]],
+        which is how the pool is indexed here."""
+        rs = self.fresh()
+        total_views = len(view_sizes)
+        if num_views < total_views:
+            kept = rs.choice(total_views, size=num_views, replace=False)
+            pool = visible_points(view_sizes, kept)
+        else:
+            pool = np.arange(int(np.sum(view_sizes)) if num_stored is None else num_stored)
+        return pool[rs.choice(len(pool), size=num_points, replace=False)]
+
+    def noise(self, std, shape):
+        return self.fresh().normal(loc=np.zeros(3), scale=np.full(3, std), size=shape)
+
+    def z_rotation(self, lo, hi):
+        angle = self.fresh().uniform(lo, hi)
+        return Rotation.from_euler("z", angle, degrees=True).as_matrix().astype(np.float32)
+
+
+def visible_points(view_sizes, kept_views):
+    """ascending indices of the stored points that belong to one of `kept_views` (views are stored back to back, view_sizes[v] points each)"""
+    owner = np.repeat(np.arange(len(view_sizes)), np.asarray(view_sizes, dtype=np.int64))
+    return np.flatnonzero(np.isin(owner, kept_views))
+
 
 def data_io(sample_group):
-    """one sample group -> the arrays the inference path needs (data_io: 134-181, without the volume / MC-surface targets)"""
+    """one sample group of the store -> raw sample dict (data_io: 134-160, the inference subset)"""
+    raw = {key: sample_group[grp][name][:] for key, (grp, name) in RAW_ARRAYS.items()}
     attrs = sample_group.attrs
-    pc, mesh = sample_group["point_cloud"], sample_group["mesh"]
-    return {
-        "cloth_sim_verts": mesh["cloth_verts"][:],
-        "cloth_nocs_verts": mesh["cloth_nocs_verts"][:],
-        "cloth_faces_tri": mesh["cloth_faces_tri"][:],
-        "pc_nocs": pc["nocs"][:],
-        "pc_sim": pc["point"][:],
-        "pc_sim_rgb": pc["rgb"][:],
-        "pc_sizes": pc["sizes"][:],
-        "scale": attrs["scale"],
-        "grip_vertex_idx": attrs["grip_vertex_idx"],
-    }
+    raw.update({k: attrs[k] for k in RAW_ATTRS})
+    return raw
 
 
 def get_base_data(idx, data_in, num_pc_sample=6000, num_views=4, static_epoch_seed=False, cloth_sim_aabb=None):
-    """get_base_data: 183-229"""
-    rs = np.random.RandomState(seed=idx if static_epoch_seed else None)
-    all_idxs = np.arange(len(data_in["pc_sim"]))
-    all_num_views = len(data_in["pc_sizes"])
-    if num_views < all_num_views:
-        idxs_mask = np.zeros_like(all_idxs, dtype=bool)
-        selected_view_idxs = np.sort(rs.choice(all_num_views, size=num_views, replace=False))
-        view_idxs = np.concatenate([[0], np.cumsum(data_in["pc_sizes"])])
-        for i in selected_view_idxs:
-            idxs_mask[view_idxs[i]:view_idxs[i + 1]] = True
-        all_idxs = all_idxs[idxs_mask]
-    selected_idxs = rs.choice(all_idxs, size=num_pc_sample, replace=False)
-
-    pc_sim_rgb = data_in["pc_sim_rgb"][selected_idxs].astype(np.float32) / 255
-    pc_sim = data_in["pc_sim"][selected_idxs].astype(np.float32)
-    pc_nocs = data_in["pc_nocs"][selected_idxs].astype(np.float32)
-    grip_idx = data_in["grip_vertex_idx"]
-    sim_grip_point = data_in["cloth_sim_verts"][grip_idx].reshape((1, 3))
-    nocs_grip_point = data_in["cloth_nocs_verts"][grip_idx].reshape((1, 3))
-    dists = np.linalg.norm(pc_sim - sim_grip_point[0], axis=1)
-    data = {
-        "x": pc_sim_rgb,
-        "y": pc_nocs,
-        "pos": pc_sim,
-        "scale": np.array([data_in["scale"]]),
-        "sim_grip_point": sim_grip_point,
-        "nocs_grip_point": nocs_grip_point,
-        "grip_pc_idx": np.array([np.argmin(dists)]),
-        "dataset_idx": np.array([idx]),
-    }
+    """raw sample -> the un-augmented network input (get_base_data: 183-229): colour / NOCS label / position of the selected points
+    (float32; colours / 255), the grip vertex in both spaces, the selected point nearest to it, bookkeeping fields"""
+    sel = SeededDraws(idx, static_epoch_seed).point_selection(data_in["pc_sizes"], num_views, num_pc_sample, len(data_in["pc_sim"]))
+    out = {}
+    for field, (src, divisor) in POINT_FIELDS.items():
+        v = data_in[src][sel].astype(np.float32)
+        out[field] = v if divisor is None else v / np.float32(divisor)
+    g = data_in["grip_vertex_idx"]
+    grip = {"sim_grip_point": data_in["cloth_sim_verts"][g][None, :], "nocs_grip_point": data_in["cloth_nocs_verts"][g][None, :]}
+    nearest = int(np.argmin(np.linalg.norm(out["pos"] - grip["sim_grip_point"][0], axis=1)))
+    out["scale"] = np.array([data_in["scale"]])
+    out.update(grip)
+    out["grip_pc_idx"] = np.array([nearest])
+    out["dataset_idx"] = np.array([idx])
     if cloth_sim_aabb is not None:
-        aabb = np.asarray(cloth_sim_aabb)
-        data["cloth_sim_aabb"] = aabb.reshape((1,) + aabb.shape)
-    return data
+        out["cloth_sim_aabb"] = np.asarray(cloth_sim_aabb)[None]
+    return out
 
 
 def noise_augmentation(idx, data, pc_noise_std, static_epoch_seed=False):
-    """noise_augumentation: 408-423 (the sum is float64, as in the reference)"""
-    rs = np.random.RandomState(seed=idx if static_epoch_seed else None)
-    noise = rs.normal(loc=(0,) * 3, scale=(pc_noise_std,) * 3, size=data["pos"].shape)
-    out = dict(data)
-    out["pos"] = data["pos"] + noise
-    return out
+    """isotropic Gaussian jitter of the input positions (noise_augumentation: 408-423); float64 out, as numpy promotes it"""
+    jitter = SeededDraws(idx, static_epoch_seed).noise(pc_noise_std, data["pos"].shape)
+    return {**data, "pos": data["pos"] + jitter}
 
 
 def rotation_augmentation(idx, data, random_rot_range=(-90, 90), static_epoch_seed=False, volume_task_space=False):
-    """rotation_augumentation: 370-406"""
-    assert len(random_rot_range) == 2 and random_rot_range[0] <= random_rot_range[-1]
-    rs = np.random.RandomState(seed=idx if static_epoch_seed else None)
-    rot_angle = rs.uniform(*random_rot_range)
-    rot_mat = Rotation.from_euler("z", rot_angle, degrees=True).as_matrix().astype(np.float32)
-    out = dict(data)
-    for key in (("pos", "sim_grip_point") if volume_task_space else ("pos", "sim_grip_point", "gt_sim_points")):
-        if key in data:
-            out[key] = (data[key] @ rot_mat.T).astype(np.float32)
-    if volume_task_space:
-        offset_vec = np.array([0.5, 0.5, 0], dtype=np.float32)
-        for key in ("volume_query_points", "surf_query_points"):
-            if key in data:
-                out[key] = ((data[key] - offset_vec) @ rot_mat.T + offset_vec).astype(np.float32)
-    out["input_aug_rot_mat"] = rot_mat.reshape((1,) + rot_mat.shape)
-    return out
+    """random rotation about z of everything that lives in simulation space (rotation_augumentation: 370-406); the matrix is recorded as
+    `input_aug_rot_mat` (1,3,3) because predict / eval rotate the ground-truth mesh with it"""
+    lo, hi = random_rot_range
+    if lo > hi:
+        raise AssertionError("random_rot_range must be (low, high)")
+    R = SeededDraws(idx, static_epoch_seed).z_rotation(lo, hi)
+    turned = dict(data)
+    plain = TASK_SPACE_SIM_FIELDS if volume_task_space else SIM_SPACE_FIELDS
+    pivoted = TASK_SPACE_QUERY_FIELDS if volume_task_space else ()
+    turned.update({k: (data[k] @ R.T).astype(np.float32) for k in plain if k in data})
+    turned.update({k: ((data[k] - TASK_SPACE_PIVOT) @ R.T + TASK_SPACE_PIVOT).astype(np.float32) for k in pivoted if k in data})
+    turned["input_aug_rot_mat"] = R[None]
+    return turned
+
+
+def instance_split(sample_ids, dataset_split=(8, 1, 1), split_seed=0):
+    """the data module's seeded train / val / test split (prepare_data: 478-529; predict.py:63-66 iterates `prediction.subset`).
+
+    Samples sharing a `sample_id` are one garment INSTANCE and never straddle two subsets.  Instances are ordered by sorted id; with
+    n instances the subset sizes are trunc(n * share) with the remainder given to train; a RandomState(split_seed) permutation of the
+    instance order is cut in that order (train, val, test); a subset's samples = the ascending dataset indices of its instances.
+    -> {"train": idx array, "val": ..., "test": ...}"""
+    if len(dataset_split) != len(SUBSETS):
+        raise AssertionError("dataset_split = (train, val, test) shares")
+    uniq, inst_of_sample = np.unique(np.asarray(sample_ids), return_inverse=True)      # sorted ids, like the reference's group-by
+    n = len(uniq)
+    share = np.asarray(dataset_split, dtype=np.float64)
+    counts = (share / share.sum() * n).astype(np.int64)
+    counts[0] += n - counts.sum()
+    order = np.random.RandomState(seed=split_seed).permutation(n)
+    cuts = np.concatenate([[0], np.cumsum(counts)])
+    return {name: np.flatnonzero(np.isin(inst_of_sample, order[cuts[i]:cuts[i + 1]])) for i, name in enumerate(SUBSETS)}
 
 
 class GarmentInputDataset:
     """dataset[idx] -> dict of numpy arrays (the fields of the reference's Data object that the inference path and predict.py
-    read); collate() -> Batch.  Constructor arguments carry the reference's names and defaults."""
+    read); collate() -> Batch.  Constructor arguments carry the reference's names and defaults.  ``subset_indices(name)`` gives the
+    dataset indices predict iterates for ``prediction.subset = name``."""
 
     def __init__(self, zarr_path, num_pc_sample=6000, enable_augumentation=True, random_rot_range=(-90, 90), num_views=4,
-                 pc_noise_std=0, static_epoch_seed=False, volume_task_space=False, **kwargs):
-        assert num_views > 0
+                 pc_noise_std=0, static_epoch_seed=False, volume_task_space=False, dataset_split=(8, 1, 1), split_seed=0, **kwargs):
+        if num_views <= 0:
+            raise AssertionError("num_views > 0")
         root = zarr_store.open_group(zarr_path, create=False)
         self.samples_group = root["samples"]
         self.keys = sorted(self.samples_group.keys())
         self.num_pc_sample, self.enable_augumentation, self.random_rot_range = num_pc_sample, enable_augumentation, tuple(random_rot_range)
         self.num_views, self.pc_noise_std, self.static_epoch_seed, self.volume_task_space = num_views, pc_noise_std, static_epoch_seed, volume_task_space
+        self.dataset_split, self.split_seed = tuple(dataset_split), split_seed
         self.cloth_sim_aabb = root["summary"]["cloth_aabb_union"][:].astype(np.float32)
+        self._split = None
 
     def __len__(self):
         return len(self.keys)
 
+    def sample_ids(self):
+        """`sample_id` attribute of every sample, in dataset order (a store without the attribute: every sample its own instance)"""
+        return [self.samples_group[k].attrs.get("sample_id", k) for k in self.keys]
+
+    def subset_indices(self, subset):
+        if subset not in SUBSETS:
+            raise KeyError(f"subset {subset!r}: expected one of {SUBSETS}")
+        if self._split is None:
+            self._split = instance_split(self.sample_ids(), self.dataset_split, self.split_seed)
+        return self._split[subset]
+
     def __getitem__(self, idx):
-        data_in = data_io(self.samples_group[self.keys[idx]])
-        data = get_base_data(idx, data_in, self.num_pc_sample, self.num_views, self.static_epoch_seed, self.cloth_sim_aabb)
-        data["input_aug_rot_mat"] = np.expand_dims(np.eye(3, dtype=np.float32), axis=0)
+        idx = int(idx)
+        sample = get_base_data(idx, data_io(self.samples_group[self.keys[idx]]), self.num_pc_sample, self.num_views,
+                               self.static_epoch_seed, self.cloth_sim_aabb)
+        sample["input_aug_rot_mat"] = np.eye(3, dtype=np.float32)[None]
         if self.pc_noise_std > 0:
-            data = noise_augmentation(idx, data, self.pc_noise_std, self.static_epoch_seed)
+            sample = noise_augmentation(idx, sample, self.pc_noise_std, self.static_epoch_seed)
         if self.enable_augumentation:
-            data = rotation_augmentation(idx, data, self.random_rot_range, self.static_epoch_seed, self.volume_task_space)
-        return data
+            sample = rotation_augmentation(idx, sample, self.random_rot_range, self.static_epoch_seed, self.volume_task_space)
+        return sample
 
     @staticmethod
     def collate(samples):

@@ -10,16 +10,75 @@
     samples/<key>/.zattrs  {scale, gender, sample_id, garment_name, grip_vertex_idx, batch_idx}
 (predict.write_prediction_sample assembles a sample; the gt_* parts exist for dataset samples only),
 each array stored as ONE chunk (chunks == shape) and read back by eval.py through `zarr` (eval.py:58-102,185-257,904-935).
-This writer emits spec-conformant Zarr v2 metadata (`.zgroup`, `.zattrs`, `.zarray`, chunk files "0.0...") with
-`compressor: null` or the stdlib `zlib` codec (`{"id": "zlib", "level": n}`), both readable by any Zarr v2 implementation;
-the reference's Blosc/zstd codec needs `numcodecs`, which is not available offline -- the codec is a storage detail, the
-group / array / dtype / shape contract is what eval.py depends on.
+This writer emits spec-conformant Zarr v2 metadata (`.zgroup`, `.zattrs`, `.zarray`, chunk files "0.0...").  Codecs:
+`compressor: null` and the stdlib `zlib` codec (`{"id": "zlib", "level": n}`) are handled here; every other codec (and any filter
+chain) goes through `numcodecs.get_codec(config)` when that package is importable -- so on a machine with numcodecs the real
+GarmentNets dataset (Blosc chunks) is readable, and ``REFERENCE_COMPRESSOR`` writes predict.py:77's
+Blosc(cname='zstd', clevel=6, shuffle=BITSHUFFLE).  ``default_compressor()`` picks that codec when numcodecs is there and zlib
+level 1 otherwise (numcodecs is not installable in the offline build image; tests exercise the branch with a stand-in module).
 """
+import importlib
 import json
 import os
 import zlib
 
 import numpy as np
+
+# predict.py:77 -- Blosc(cname='zstd', clevel=6, shuffle=Blosc.BITSHUFFLE) as a Zarr v2 codec config (BITSHUFFLE == 2)
+REFERENCE_COMPRESSOR = {"id": "blosc", "cname": "zstd", "clevel": 6, "shuffle": 2, "blocksize": 0}
+
+
+def _numcodecs():
+    """the numcodecs module or None (looked up at call time: an environment that gains the package needs no re-import of this one)"""
+    try:
+        return importlib.import_module("numcodecs")
+    except ImportError:
+        return None
+
+
+def default_compressor():
+    """the reference's codec when it can be written here, the stdlib one otherwise"""
+    return dict(REFERENCE_COMPRESSOR) if _numcodecs() is not None else ("zlib", 1)
+
+
+def _codec_config(compressor):
+    """None | ("zlib", level) | a Zarr v2 codec config dict -> config dict or None"""
+    if compressor is None:
+        return None
+    if isinstance(compressor, dict):
+        return dict(compressor)
+    cid, level = compressor
+    if cid != "zlib":
+        raise ValueError(f"compressor {compressor!r}: pass a codec config dict for anything but ('zlib', level)")
+    return {"id": "zlib", "level": int(level)}
+
+
+class _Codec:
+    """encode / decode for one codec config: zlib from the standard library, the rest from numcodecs"""
+
+    def __init__(self, config, what=""):
+        self.config, self.impl = config, None
+        if config is not None and config.get("id") != "zlib":
+            nc = _numcodecs()
+            if nc is None:
+                raise NotImplementedError(f"{what}: codec {config.get('id')!r} needs the numcodecs package (only zlib / uncompressed chunks "
+                                          f"are handled without it)")
+            self.impl = nc.get_codec(config)
+
+    def encode(self, raw):
+        if self.config is None:
+            return raw
+        if self.impl is not None:
+            return bytes(self.impl.encode(raw))
+        return zlib.compress(raw, self.config.get("level", 1))
+
+    def decode(self, raw):
+        if self.config is None:
+            return raw
+        if self.impl is not None:
+            out = self.impl.decode(raw)
+            return out.tobytes() if isinstance(out, np.ndarray) else bytes(out)
+        return zlib.decompress(raw)
 
 
 def _write_json(path, obj):
@@ -51,15 +110,13 @@ class Group:
 
     def array(self, name, data, chunks=None, compressor=None, overwrite=True):
         """C-order Zarr v2 array; chunks=None -> one chunk (chunks == data.shape: what the reference's prediction.zarr uses), else a
-        chunk grid with full-size (fill-padded) edge chunks; compressor: None or ("zlib", level)"""
+        chunk grid with full-size (fill-padded) edge chunks; compressor: None, ("zlib", level) or a Zarr v2 codec config dict
+        (e.g. REFERENCE_COMPRESSOR; anything but zlib needs numcodecs)"""
         data = np.ascontiguousarray(data)
         apath = os.path.join(self.path, name)
+        comp = _codec_config(compressor)
+        codec = _Codec(comp, apath)
         os.makedirs(apath, exist_ok=True)
-        comp = None
-        if compressor is not None:
-            cid, level = compressor
-            assert cid == "zlib"
-            comp = {"id": "zlib", "level": int(level)}
         shape = list(data.shape)
         cshape = shape if chunks is None else [int(c) for c in chunks]
         assert len(cshape) == len(shape)
@@ -75,9 +132,7 @@ class Group:
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = data[sl]
             else:
                 block = data
-            raw = np.ascontiguousarray(block).tobytes()
-            if comp is not None:
-                raw = zlib.compress(raw, comp["level"])
+            raw = codec.encode(np.ascontiguousarray(block).tobytes())
             with open(os.path.join(apath, ".".join(str(i) for i in ci) if ci else "0"), "wb") as f:
                 f.write(raw)
 
@@ -111,15 +166,14 @@ class Group:
 
 def _read_array(path):
     """Zarr v2 array -> numpy: any chunk grid (C order, '.' or '/' chunk keys, edge chunks stored full-size, missing chunks =
-    fill_value), compressor None or zlib (Blosc needs numcodecs, which is not installable offline: reported, not guessed)."""
+    fill_value), compressor None / zlib natively, any other codec and any filter chain through numcodecs when importable (reported,
+    not guessed, when it is not)."""
     meta = json.load(open(os.path.join(path, ".zarray")))
     shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
     dtype = np.dtype(meta["dtype"])
     comp = meta.get("compressor")
-    if comp is not None and comp.get("id") != "zlib":
-        raise NotImplementedError(f"{path}: compressor {comp.get('id')!r} needs numcodecs (only zlib / uncompressed chunks are readable here)")
-    if meta.get("filters"):
-        raise NotImplementedError(f"{path}: filters are not supported")
+    codec = _Codec(comp, path)
+    filters = [_Codec(f, path) for f in (meta.get("filters") or [])]
     if meta.get("order", "C") != "C":
         raise NotImplementedError(f"{path}: only C-order chunks are supported")
     sep = meta.get("dimension_separator", ".")
@@ -133,9 +187,9 @@ def _read_array(path):
         f = os.path.join(path, sep.join(str(i) for i in ci) if ci else "0")
         if not os.path.exists(f):
             continue
-        raw = open(f, "rb").read()
-        if comp is not None:
-            raw = zlib.decompress(raw)
+        raw = codec.decode(open(f, "rb").read())
+        for flt in reversed(filters):
+            raw = flt.decode(raw)
         block = np.frombuffer(raw, dtype=dtype).reshape(chunks if shape else ())
         if not shape:
             out[...] = block
@@ -145,16 +199,15 @@ def _read_array(path):
     return out
 
 
-CODEC_NOTE = ("chunks are stored with Zarr v2's stdlib codec {'id': 'zlib'} (or uncompressed) instead of the reference's "
-              "Blosc(cname='zstd', clevel=6, shuffle=BITSHUFFLE) (predict.py:77): numcodecs is not available offline; group / array / dtype / "
-              "shape layout is the reference's")
+CODEC_NOTE = ("written without numcodecs: chunks use Zarr v2's stdlib codec {'id': 'zlib'} (or none) instead of the reference's "
+              "Blosc(cname='zstd', clevel=6, shuffle=BITSHUFFLE) (predict.py:77); group / array / dtype / shape layout is the reference's")
 
 
 def open_group(path, create=True):
     """root group of a store; a store created here records the one deviation from the reference's on-disk format in its .zattrs"""
     fresh = create and not os.path.exists(os.path.join(path, ".zgroup"))
     g = Group(path, create=create)
-    if fresh:
+    if fresh and _numcodecs() is None:
         g.put_attrs({"codec_note": CODEC_NOTE})
     return g
 
@@ -170,8 +223,10 @@ def copy_group(src_group, dst_parent, name):
     return Group(dst, create=False)
 
 
-def write_sample(samples_group, key, mesh, point_cloud, misc, attrs=None, compressor=("zlib", 1)):
-    """Write one prediction sample in the reference's layout (predict.py:211-279)."""
+def write_sample(samples_group, key, mesh, point_cloud, misc, attrs=None, compressor="default"):
+    """Write one prediction sample in the reference's layout (predict.py:211-279); compressor "default" = default_compressor()."""
+    if compressor == "default":
+        compressor = default_compressor()
     g = samples_group.require_group(key)
     if attrs:
         g.put_attrs(attrs)

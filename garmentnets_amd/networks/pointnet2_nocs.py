@@ -41,6 +41,14 @@ class PointNet2NOCS(nn.Module):
     def device(self):
         return self.lin1.weight.device
 
+    def set_self_loop_scope(self, scope):
+        """"batch" (default; PyG's literal PointConv rule on a batched graph) or "example" (every garment of a batch gets its batch-of-one
+        result: what the reference's predict.py, which asserts batch_size == 1, produces) -- components/pointnet2.py PointConv"""
+        if scope not in ("batch", "example"):
+            raise ValueError(f"self_loop_scope={scope!r}")
+        self.sa1_module.conv.self_loop_scope = self.sa2_module.conv.self_loop_scope = scope
+        return self
+
     def forward(self, data):
         """data: .x (N,3) rgb, .pos (N,3), .batch (N,) sorted int64 [, .sizes host list] -- eval mode (dropout = identity)."""
         sizes = data._sizes if hasattr(data, "_sizes") else getattr(data, "sizes", None)

@@ -5,6 +5,7 @@ current torch stream.  Tensors must live on a ROCm device -- there is no CPU pat
 """
 import ctypes
 import math
+import threading
 
 import numpy as np
 import torch
@@ -14,13 +15,19 @@ from . import _lib
 _i32 = torch.int32
 
 
-_ARG_DEVICE = [None]     # device of the tensors of the call being assembled (arguments are evaluated left to right, _stream() last)
+class _CallState(threading.local):
+    """per HOST THREAD: the device of the tensors of the C-ABI call being assembled (arguments are evaluated left to right, _stream()
+    last).  Thread-local, so two threads driving two models / devices never see each other's half-assembled call"""
+    dev = None
+
+
+_CALL = _CallState()
 
 
 def _stream():
     """torch's current stream ON THE DEVICE OF THE CALL'S TENSORS (not of torch's current device: a model on cuda:1 with the
     process default device 0 must launch on cuda:1's stream; the C ABI binds the HIP device to the stream's, csrc/common.h gn_stream)"""
-    dev, _ARG_DEVICE[0] = _ARG_DEVICE[0], None
+    dev, _CALL.dev = _CALL.dev, None
     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
         torch.cuda.set_device(dev)            # the null stream means "current device" to HIP: make the two agree
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -31,10 +38,10 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise _lib.GarmentNetsHipError("garmentnets_amd ops need tensors on the GPU (no CPU fallback)")
-    if _ARG_DEVICE[0] is None:
-        _ARG_DEVICE[0] = t.device
-    elif _ARG_DEVICE[0] != t.device:
-        dev, _ARG_DEVICE[0] = _ARG_DEVICE[0], None
+    if _CALL.dev is None:
+        _CALL.dev = t.device
+    elif _CALL.dev != t.device:
+        dev, _CALL.dev = _CALL.dev, None
         raise _lib.GarmentNetsHipError(f"garmentnets_amd ops: tensors on different devices ({dev} vs {t.device})")
     return ctypes.c_void_p(t.data_ptr())
 
@@ -93,15 +100,16 @@ def ball_query(pos, ptr, centre_idx, centre_ptr, r, K=64):
     return nbr, cnt
 
 
-def sa_gather(x, pos, centre_idx, nbr, self_loops=True):
+def sa_gather(x, pos, centre_idx, nbr, self_loops=True, self_src=None):
+    """self_src: int32 [M] scope of the self-loop rule (include/garmentnets_hip.h: gn_sa_gather_scoped) or None = PyG's literal rule"""
     M, K = nbr.shape
     C = 0 if x is None else x.shape[1]
     S = K + (1 if self_loops else 0)
     out = new_rows(M * S, C + 3, pos.device)
     slot_src = torch.empty(M * S, dtype=_i32, device=pos.device)
     ldx = 0 if x is None else rows_view(x)[1]
-    _lib.call("gn_sa_gather", _p(x), ldx, C, _p(pos), _p(centre_idx), _p(nbr), M, K, 1 if self_loops else 0, _p(out),
-              out.stride(0), _p(slot_src), _stream())
+    _lib.call("gn_sa_gather_scoped", _p(x), ldx, C, _p(pos), _p(centre_idx), _p(nbr), M, K, 1 if self_loops else 0,
+              _p(_chk(self_src, _i32, "self_src") if self_src is not None else None), _p(out), out.stride(0), _p(slot_src), _stream())
     return out, slot_src, S
 
 
@@ -153,13 +161,13 @@ def pack_sa_fused(layers):
     return SaFusedPack(packs[0], packs[1], packs[2], torch.cat(tabs).contiguous(), cin, dims)
 
 
-def sa_fused(x, pos, centre_idx, nbr, cnt, pack, self_loops=True):
+def sa_fused(x, pos, centre_idx, nbr, cnt, pack, self_loops=True, self_src=None):
     """fps centres + ball-query table -> [M][n3] set-abstraction features (PointConv(local_nn, max) in one kernel, csrc/sa_fused.hip)"""
     M, K = nbr.shape
     out = new_rows(M, pack.cout, pos.device)
     ldx = 0 if x is None else rows_view(x)[1]
-    _lib.call("gn_sa_fused", _p(x), ldx, pack.cin, _p(_chk(pos, torch.float32, "pos")), _p(centre_idx), _p(nbr), _p(cnt), M, K, 1 if self_loops else 0,
-              _p(pack.w1p), _p(pack.w2p), _p(pack.w3p), _p(pack.tab), pack.dims[0], pack.dims[1], pack.dims[2], _p(out), out.stride(0), _stream())
+    _lib.call("gn_sa_fused_scoped", _p(x), ldx, pack.cin, _p(_chk(pos, torch.float32, "pos")), _p(centre_idx), _p(nbr), _p(cnt), M, K, 1 if self_loops else 0,
+              _p(_chk(self_src, _i32, "self_src") if self_src is not None else None), _p(pack.w1p), _p(pack.w2p), _p(pack.w3p), _p(pack.tab), pack.dims[0], pack.dims[1], pack.dims[2], _p(out), out.stride(0), _stream())
     return out
 
 

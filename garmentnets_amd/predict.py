@@ -15,7 +15,9 @@ augmentation rotation, point_cloud/gt_nocs, misc/gt_nocs_grip_point, per-sample 
 Hydra / wandb are out of scope.
 """
 import argparse
+import collections
 import json
+import threading
 import time
 
 import numpy as np
@@ -36,25 +38,54 @@ def nan_placeholder(device):
                 volume_gradient_magnitude=torch.full((1,), float("nan"), device=device), warp_field=nan3.clone())
 
 
-_FALLBACKS = {"count": 0}
+class _Counter:
+    """fp32 re-runs seen by this process (any thread); ``["count"]`` reads it"""
+
+    def __init__(self):
+        self._lock, self._n = threading.Lock(), 0
+
+    def bump(self):
+        with self._lock:
+            self._n += 1
+            return self._n
+
+    def __getitem__(self, key):
+        if key != "count":
+            raise KeyError(key)
+        with self._lock:
+            return self._n
+
+    def __setitem__(self, key, value):          # tests reset it
+        if key != "count":
+            raise KeyError(key)
+        with self._lock:
+            self._n = int(value)
+
+
+_FALLBACKS = _Counter()
+_CAPS_LOCK = threading.Lock()
+ISO_CAP_LATTICES = 4         # _iso_capacity remembers at most this many lattice sizes per model
 
 
 def _iso_capacity(model, Q, needed=None):
     """per-model memory of how many vertices the iso-surfaces of this model's volumes have asked for (keyed by lattice size): the batched
     MC33 launch sizes its output buffers from it (+25 %), so that a checkpoint whose surfaces are larger than the garment-like default
     (6 Q^2 vertices) pays the one-volume-at-a-time redo once, not every batch.  needed: record a finished batch's demand"""
-    caps = model.__dict__.setdefault("_iso_caps", {})
-    if needed is not None:
-        if needed > caps.get(Q, 0):
-            caps[Q] = int(needed)
-        return None
-    return int(caps[Q] * 1.25) + 1024 if Q in caps else None
+    with _CAPS_LOCK:
+        caps = model.__dict__.setdefault("_iso_caps", collections.OrderedDict())
+        if needed is not None:
+            # grows at once, decays slowly (1/8 of the gap per batch): one outlier batch does not pin tens of MB of output buffers for good
+            have = caps.pop(Q, 0)
+            caps[Q] = int(needed) if needed >= have else have - (have - int(needed)) // 8
+            while len(caps) > ISO_CAP_LATTICES:
+                caps.popitem(last=False)
+            return None
+        return int(caps[Q] * 1.25) + 1024 if Q in caps else None
 
 
 def _warn_fallback():
     import warnings
-    _FALLBACKS["count"] += 1
-    if _FALLBACKS["count"] == 1:
+    if _FALLBACKS.bump() == 1:
         warnings.warn("garmentnets_amd: NaN in the WNF volume / warp field / hole logits under the split-operand arithmetic (a value left "
                       "fp16's range, or the input holds NaN): re-running the batch with the fp32 kernels")
 
@@ -187,7 +218,15 @@ def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_s
     return _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan, arith)
 
 
-_TAIL_STREAMS = {}
+_TAIL = threading.local()         # per host thread: {device: its tail stream} -- two threads driving PredictJobs never share one
+
+
+def _tail_stream(device):
+    streams = _TAIL.__dict__.setdefault("streams", {})
+    key = str(device)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=device)
+    return streams[key]
 
 
 class PredictJob:
@@ -215,9 +254,7 @@ class PredictJob:
         batch only, not for the next batch's dense path on the caller's stream)"""
         volume_size, level, sigma, direction, hole = self.args
         split = self.arith.split
-        tail = _TAIL_STREAMS.get(str(self.device))
-        if tail is None:
-            tail = _TAIL_STREAMS[str(self.device)] = torch.cuda.Stream(device=self.device)
+        tail = _tail_stream(self.device)
         tail.wait_event(self.ready)
         with torch.cuda.stream(tail):
             results, bad = _tail_phase(self.model, self.batch, self.state, level, sigma, direction, hole, False, split, self.arith)
@@ -314,13 +351,15 @@ def to_host_groups(res, data=None):
 SAMPLE_ATTR_KEYS = ("scale", "gender", "sample_id", "garment_name", "grip_vertex_idx")      # predict.py:124-130
 
 
-def write_prediction_sample(output_samples_group, group_key, res, data=None, input_group=None, batch_idx=0, compressor=("zlib", 1)):
+def write_prediction_sample(output_samples_group, group_key, res, data=None, input_group=None, batch_idx=0, compressor="default"):
     """one sample of prediction.zarr, predict.py:120-136,211-279: the predicted marching_cubes_mesh / point_cloud / misc groups and -- for
     a dataset sample (`data` = its one-garment Batch, `input_group` = its group in the INPUT store) -- everything eval.py reads next to
     them (eval.py:58-66,106-110,147-152,193-208): the per-sample attrs, ``gt_marching_cubes_mesh`` (a copy of the input sample's
     ``marching_cube_mesh`` group, chunk files and codec as they are: what zarr.copy does) and ``gt_mesh`` (the input ``mesh`` arrays,
     ``cloth_verts`` rotated by the augmentation matrix the cloud was rotated with)."""
     from .io import zarr_store
+    if compressor == "default":              # predict.py:77's Blosc(zstd, 6, BITSHUFFLE) when numcodecs is importable, zlib otherwise
+        compressor = zarr_store.default_compressor()
     attrs = {"batch_idx": int(batch_idx)}
     if input_group is not None:
         src = input_group.attrs
@@ -341,6 +380,11 @@ def write_prediction_sample(output_samples_group, group_key, res, data=None, inp
     return g
 
 
+def _batches_of(indices, batch_size):
+    for i in range(0, len(indices), batch_size):
+        yield indices[i:i + batch_size]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="GarmentNets predict (MI355X-native): predict.py's loop over a dataset store or synthetic clouds")
     ap.add_argument("--checkpoint_path", default=None, help="Lightning-style .ckpt; default: seeded synthetic weights")
@@ -351,20 +395,34 @@ def main(argv=None):
     ap.add_argument("--gradient_direction", default="ascent")
     ap.add_argument("--use_hole_prediction", action="store_true")
     ap.add_argument("--auto_level", action="store_true", help="synthetic weights: iso level = mid(min, max) of each WNF volume instead of the fixed level")
-    ap.add_argument("--num_samples", type=int, default=4)
+    ap.add_argument("--num_samples", type=int, default=None, help="at most this many samples (default: the whole subset of a store; 4 synthetic clouds)")
     ap.add_argument("--num_pc_sample", type=int, default=6000)
     ap.add_argument("--grid", type=int, default=32)
     ap.add_argument("--reduce_method", default="max")
-    ap.add_argument("--subset", default="test", help="prediction.subset of the reference config (recorded in the output store's root attrs)")
+    ap.add_argument("--subset", default="test", choices=("train", "val", "test", "all"),
+                    help="prediction.subset of the reference config (predict.py:63-66): the samples of the data module's seeded instance split "
+                         "(datamodule.dataset_split / split_seed); val and test read the store with static_epoch_seed=True, as the reference's "
+                         "val_dataset does.  'all' = every sample of the store, in key order")
+    ap.add_argument("--dataset_split", type=float, nargs=3, default=(8, 1, 1), help="datamodule.dataset_split (predict_default.yaml: [8,1,1])")
+    ap.add_argument("--split_seed", type=int, default=0, help="datamodule.split_seed (predict_default.yaml: 0)")
+    ap.add_argument("--batch_size", type=int, default=1,
+                    help="garments per forward pass.  1 = the reference's loop (predict.py:62 asserts it).  > 1: the batched device tail (one "
+                         "marching-cubes / surface-decode launch set per batch); PointConv's bipartite self-loop quirk then links centre i to point i "
+                         "of the WHOLE batch, as the reference's forward would at that batch size -- see --self_loop_scope")
+    ap.add_argument("--self_loop_scope", default="example", choices=("example", "batch"),
+                    help="example (default): PointConv's added self-loop of centre i is point i of the centre's OWN cloud, so every garment of a batch "
+                         "gets exactly its batch_size=1 result; batch: PyG's literal behaviour on a batched graph (point i of the concatenated cloud)")
+    ap.add_argument("--in_flight", type=int, default=2, choices=(1, 2), help="2 (default): batch k+1's dense path is queued before batch k's tail is "
+                                                                              "finished (predict_stream); 1: one batch at a time (predict_batch)")
     ap.add_argument("--out", default=None, help="optional .npz with the last mesh")
     ap.add_argument("--zarr_out", default=None, help="optional prediction.zarr directory (reference group layout, Zarr v2)")
-    ap.add_argument("--zarr_in", default=None, help="garmentnets dataset (Zarr v2, zlib / uncompressed chunks): read the clouds through "
+    ap.add_argument("--zarr_in", default=None, help="garmentnets dataset (Zarr v2; Blosc chunks need numcodecs): read the clouds through "
                                                     "io.dataset.GarmentInputDataset instead of synthetic ones; with --zarr_out the ground-truth groups eval.py "
                                                     "reads are written too")
     ap.add_argument("--num_views", type=int, default=4)
     ap.add_argument("--no_augmentation", action="store_true", help="datamodule.enable_augumentation=False (predict_default.yaml: True)")
     ap.add_argument("--random_rot_range", type=float, nargs=2, default=(-180.0, 180.0))
-    ap.add_argument("--static_epoch_seed", action="store_true", help="datamodule.static_epoch_seed=True (predict_default.yaml: False)")
+    ap.add_argument("--static_epoch_seed", action="store_true", help="force static_epoch_seed=True for --subset train / all too")
     a = ap.parse_args(argv)
     device = torch.device("cuda:{}".format(a.gpu_id))
     torch.cuda.set_device(device)       # main.gpu_id of the reference config: every allocation, stream and kernel of this process goes there
@@ -375,37 +433,68 @@ def main(argv=None):
         model = ConvImplicitWNFPipeline(**hp)
         model.load_state_dict(synthetic.synthetic_state_dict(hp, 0))
     model = model.to(device).eval().requires_grad_(False)
-    last = None
+    model.pointnet2_nocs.set_self_loop_scope(a.self_loop_scope)
     dataset = None
     if a.zarr_in:
         from .io.dataset import GarmentInputDataset
-        dataset = GarmentInputDataset(a.zarr_in, num_pc_sample=a.num_pc_sample, num_views=a.num_views, static_epoch_seed=a.static_epoch_seed,
+        dataset = GarmentInputDataset(a.zarr_in, num_pc_sample=a.num_pc_sample, num_views=a.num_views,
+                                      static_epoch_seed=a.static_epoch_seed or a.subset in ("val", "test"),
                                       enable_augumentation=not a.no_augmentation, random_rot_range=tuple(a.random_rot_range),
-                                      volume_task_space=model.volume_task_space)
+                                      volume_task_space=model.volume_task_space, dataset_split=tuple(a.dataset_split), split_seed=a.split_seed)
+        indices = list(range(len(dataset))) if a.subset == "all" else [int(i) for i in dataset.subset_indices(a.subset)]
+    else:
+        indices = list(range(4 if a.num_samples is None else a.num_samples))
+    if a.num_samples is not None:
+        indices = indices[:a.num_samples]
     out_samples = None
     if a.zarr_out:
         from .io import zarr_store
         root = zarr_store.open_group(a.zarr_out)
         root.put_attrs({"subset": a.subset if dataset is not None else "synthetic"})
         out_samples = root.require_group("samples")
-    for i in range(min(a.num_samples, len(dataset)) if dataset is not None else a.num_samples):   # batch_size == 1 as asserted by predict.py:62
-        if dataset is not None:
-            data = GarmentInputDataset.collate([dataset[i]])
-        else:
-            x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
-            data = Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch)
-        t0 = time.time()
-        res = predict_batch(model, data.to(device), a.volume_size, a.iso_surface_level, a.gradient_sigma, a.gradient_direction, a.use_hole_prediction,
-                            auto_level=a.auto_level)[0]
-        last = to_host(res)
-        if out_samples is not None:
+
+    def load(chunk):
+        """-> (per-garment (key, one-garment Batch, input group), the batch on the device)"""
+        items = []
+        for i in chunk:
             if dataset is not None:
-                write_prediction_sample(out_samples, dataset.keys[i], res, data, dataset.samples_group[dataset.keys[i]], batch_idx=i)
+                key = dataset.keys[i]
+                items.append((key, GarmentInputDataset.collate([dataset[i]]), dataset.samples_group[key]))
             else:
-                write_prediction_sample(out_samples, f"synthetic_{i:05d}", res, batch_idx=i)
-        torch.cuda.synchronize()
-        print(json.dumps({"sample": i, "verts": int(last["verts"].shape[0]), "faces": int(last["faces"].shape[0]),
-                          "seconds": round(time.time() - t0, 4)}))
+                x, pos, batch = synthetic.synthetic_cloud(1, a.num_pc_sample, seed=i)
+                items.append((f"synthetic_{i:05d}", Batch(sizes=[a.num_pc_sample], x=x, pos=pos, batch=batch), None))
+        if len(items) == 1:
+            return items, items[0][1].to(device)
+        sizes = [it[1].sizes[0] for it in items]
+        joint = Batch(sizes=sizes, x=torch.cat([it[1].x for it in items]), pos=torch.cat([it[1].pos for it in items]),
+                      batch=torch.repeat_interleave(torch.arange(len(items)), torch.tensor(sizes)))
+        return items, joint.to(device)
+
+    kw = dict(volume_size=a.volume_size, iso_surface_level=a.iso_surface_level, gradient_sigma=a.gradient_sigma,
+              gradient_direction=a.gradient_direction, use_hole_prediction=a.use_hole_prediction)
+    pending = collections.deque()
+
+    def inputs():
+        for chunk in _batches_of(indices, a.batch_size):
+            items, dev_batch = load(chunk)
+            pending.append((items, time.time()))
+            yield dev_batch
+
+    if a.in_flight == 2 and not a.auto_level:
+        results_iter = predict_stream(model, inputs(), **kw)
+    else:
+        results_iter = (predict_batch(model, b, auto_level=a.auto_level, **kw) for b in inputs())
+    last, batch_idx = None, 0
+    for results in results_iter:
+        items, t0 = pending.popleft()
+        for (key, data, input_group), res in zip(items, results):
+            last = to_host(res)
+            if out_samples is not None:
+                write_prediction_sample(out_samples, key, res, data if dataset is not None else None, input_group, batch_idx=batch_idx)
+            print(json.dumps({"sample": batch_idx, "key": key, "verts": int(last["verts"].shape[0]), "faces": int(last["faces"].shape[0]),
+                              "seconds_since_load": round(time.time() - t0, 4)}))
+            batch_idx += 1
+    torch.cuda.synchronize()
     if a.out and last is not None:
         np.savez_compressed(a.out, **last)
 

@@ -71,6 +71,12 @@ int gn_ball_query(const float *pos, const int32_t *ptr, const int32_t *centre_id
  * x may be NULL (C=0). */
 int gn_sa_gather(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
                  int M, int K, int self_loops, float *out, int ldo, int32_t *slot_src, void *stream);
+/* The same with the self-loop rule scoped by the caller: self_src[c] (int32 [M], or NULL = c: the call above) is the point that plays
+ * "node c" on the source side -- dropped from centre c's neighbours, and the source of its added loop.  With self_src[c] = ptr[b] +
+ * (c - centre_ptr[b]) (b = the centre's example) every example of a batch gets exactly what a batch of one would give it:
+ * predict.py:62 asserts batch_size == 1, so that is the result the reference's pipeline produces for a garment. */
+int gn_sa_gather_scoped(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
+                        int M, int K, int self_loops, const int32_t *self_src, float *out, int ldo, int32_t *slot_src, void *stream);
 
 /* out[c][ch] = max over valid slots s of in[c*S+s][ch].  replaces PointConv aggr='max' (scatter-max). */
 int gn_segment_max(const float *in, int ldi, const int32_t *slot_src, int M, int S, int C, float *out, int ldo,
@@ -88,6 +94,10 @@ int gn_sa_fused_supported(int C, int N1, int N2, int N3);
 int gn_sa_fused(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr, const int32_t *cnt,
                 int M, int K, int self_loops, const float *w1p, const float *w2p, const float *w3p, const float *tab, int N1, int N2,
                 int N3, float *out, int ldo, void *stream);
+/* gn_sa_fused with the caller-scoped self-loop rule of gn_sa_gather_scoped (self_src: int32 [M] or NULL). */
+int gn_sa_fused_scoped(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr, const int32_t *cnt,
+                       int M, int K, int self_loops, const int32_t *self_src, const float *w1p, const float *w2p, const float *w3p,
+                       const float *tab, int N1, int N2, int N3, float *out, int ldo, void *stream);
 
 /* out[b][ch] = max over rows ptr[b]..ptr[b+1].  replaces PyG global_max_pool -- components/pointnet2.py:49. */
 int gn_global_max_pool(const float *in, int ldi, const int32_t *ptr, int B, int C, float *out, int ldo, void *stream);

@@ -54,8 +54,9 @@ def mlp(sd, prefix, x):
 
 
 # ------------------------------------------------------------------------------------------------ PointNet++
-def sa_module(sd, prefix, x, pos, ptr, ratio, r, self_loops=True, return_graph=False):
-    """components/pointnet2.py:22-33 + PyG PointConv(add_self_loops=True, aggr='max')."""
+def sa_module(sd, prefix, x, pos, ptr, ratio, r, self_loops=True, return_graph=False, self_loop_scope="batch"):
+    """components/pointnet2.py:22-33 + PyG PointConv(add_self_loops=True, aggr='max').  self_loop_scope "example": the self-loop rule
+    applied per example (node i of a centre = point i of its own cloud), i.e. the batch-of-one result for every example"""
     idx, cptr = O.fps(pos.numpy(), ptr, ratio)
     nbr, cnt = O.ball_query(pos.numpy(), ptr, idx, cptr, r, 64)
     M = len(idx)
@@ -64,6 +65,8 @@ def sa_module(sd, prefix, x, pos, ptr, ratio, r, self_loops=True, return_graph=F
         # PointConv quirk on the bipartite graph: remove edges whose numeric source == target index, then
         # add (i, i) for i < M: centre i also receives POINT i of the full cloud.
         ar = torch.arange(M).unsqueeze(1)
+        if self_loop_scope == "example":
+            ar = torch.cat([ptr[b] + torch.arange(cptr[b + 1] - cptr[b]) for b in range(len(ptr) - 1)]).unsqueeze(1)
         nbr_t = torch.where(nbr_t == ar, torch.full_like(nbr_t, -1), nbr_t)
         nbr_t = torch.cat([nbr_t, ar], dim=1)
     valid = nbr_t >= 0

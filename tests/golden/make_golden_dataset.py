@@ -74,6 +74,29 @@ def main():
             out[f"c{ci}/base/{k}"] = np.asarray(v)
         for k, v in final.items():
             out[f"c{ci}/final/{k}"] = np.asarray(v)
+    # the data module's seeded instance split (prepare_data: 478-529), run unmodified; only the dataset class it instantiates is swapped
+    # for a bare object carrying the `groups_df` / `static_epoch_seed` attributes prepare_data reads (the real one needs zarr)
+    import pandas as pd
+    split_cases = [dict(n_inst=37, views=(1, 5), split=(8, 1, 1), seed=0), dict(n_inst=10, views=(2, 3), split=(8, 1, 1), seed=0),
+                   dict(n_inst=123, views=(1, 4), split=(6, 3, 1), seed=42)]
+    for si, c in enumerate(split_cases):
+        rs = np.random.RandomState(900 + si)
+        ids = np.concatenate([np.full(rs.randint(*c["views"]), i) for i in rs.permutation(c["n_inst"])])
+        rs.shuffle(ids)                                                    # instances interleaved in dataset order
+        sample_ids = np.array([f"{v:05d}_Dress" for v in ids])
+        keys = [f"{k:06d}" for k in range(len(sample_ids))]
+
+        class FakeDataset:
+            def __init__(self, **kw):
+                self.static_epoch_seed = kw.get("static_epoch_seed", False)
+                self.groups_df = pd.DataFrame({"sample_id": sample_ids, "group_key": keys, "idx": np.arange(len(keys))}, index=keys)
+
+        ref_mod.ConvImplicitWNFDataset = FakeDataset
+        dm = ref_mod.ConvImplicitWNFDataModule(dataset_split=c["split"], split_seed=c["seed"], batch_size=1, num_workers=0)
+        dm.prepare_data()
+        out[f"s{si}/sample_ids"] = sample_ids
+        out[f"s{si}/params"] = np.array(list(c["split"]) + [c["seed"]])
+        out[f"s{si}/train"], out[f"s{si}/val"], out[f"s{si}/test"] = (np.asarray(v, dtype=np.int64) for v in (dm.train_idxs, dm.val_idxs, dm.test_idxs))
     np.savez_compressed(os.path.join(HERE, "ref_dataset.npz"), **out)
     print("wrote ref_dataset.npz:", len(out), "arrays")
 

@@ -429,8 +429,8 @@ def test_predict_main_writes_the_store_eval_reads(tmp_path):
     din, dout = str(tmp_path / "garmentnets_dataset.zarr"), str(tmp_path / "prediction.zarr")
     keys = _write_synthetic_dataset(din, 2, rng)
     PR.main(["--zarr_in", din, "--zarr_out", dout, "--num_samples", "2", "--num_pc_sample", "1800", "--num_views", "3", "--grid", "16", "--volume_size", "24",
-             "--auto_level", "--static_epoch_seed", "--random_rot_range", "-180", "180", "--subset", "test"])
-    assert json.load(open(os.path.join(dout, ".zattrs")))["subset"] == "test"
+             "--auto_level", "--static_epoch_seed", "--random_rot_range", "-180", "180", "--subset", "all"])
+    assert json.load(open(os.path.join(dout, ".zattrs")))["subset"] == "all"
     ds = GarmentInputDataset(din, num_pc_sample=1800, num_views=3, static_epoch_seed=True, enable_augumentation=True, random_rot_range=(-180, 180))
     hp = S.default_hparams(grid=16, reduce_method="max")
     model = _model(hp, 0)
@@ -468,6 +468,138 @@ def test_predict_main_writes_the_store_eval_reads(tmp_path):
         assert np.array_equal(rd("gt_mesh", "cloth_verts"), cv @ rot.T)
         for k in ("cloth_nocs_verts", "cloth_faces_tri"):
             assert np.array_equal(rd("gt_mesh", k), _zarr_v2_read(din, os.path.join(base, "mesh", k))), k
+
+
+def test_self_loop_scope_example_gives_every_garment_its_batch_of_one_result():
+    """PointConv's bipartite self-loop rule scoped per example (gn_sa_fused_scoped / gn_sa_gather_scoped, PointNet2NOCS.set_self_loop_scope):
+    a ragged batch of four garments through the HIP path == the ORACLE run on each garment alone (batch of one: what predict.py, which
+    asserts batch_size == 1, computes) -- and bit-equal to the HIP path's own batch-of-one runs; with the default "batch" scope the slots
+    behind the first legitimately differ"""
+    hp = S.default_hparams(grid=16, reduce_method="max")
+    sd = S.synthetic_state_dict(hp, 11)
+    sizes = [1500, 2100, 1800, 1500]
+    clouds = [S.synthetic_cloud(1, n, seed=300 + i) for i, n in enumerate(sizes)]
+    x, pos = torch.cat([c[0] for c in clouds]), torch.cat([c[1] for c in clouds])
+    batch = torch.repeat_interleave(torch.arange(4), torch.tensor(sizes))
+    data = Batch(sizes=sizes, x=x, pos=pos, batch=batch).to(DEV)
+    for fused in (True, False):
+        import garmentnets_amd.components.pointnet2 as CP
+        saved = CP.FUSED_SA
+        CP.FUSED_SA = fused
+        try:
+            model = _model(hp, 11)
+            model.pointnet2_nocs.set_self_loop_scope("example")
+            with torch.no_grad():
+                got = model.pointnet2_forward(data)
+                lo = 0
+                for i, n in enumerate(sizes):
+                    cx, cp, cb = clouds[i]
+                    ref = P.pointnet2_forward(sd, hp, cx, cp, cb)
+                    one = model.pointnet2_forward(Batch(sizes=[n], x=cx, pos=cp, batch=cb).to(DEV))
+                    sl = slice(lo, lo + n)
+                    assert torch.equal(got["per_point_logits"][sl], one["per_point_logits"]), (fused, i)
+                    assert torch.equal(got["global_feature"][i], one["global_feature"][0]), (fused, i)
+                    assert float((got["per_point_logits"][sl].cpu() - ref["per_point_logits"]).abs().max()) <= TOL
+                    assert float((got["global_feature"][i].cpu() - ref["global_feature"][0]).abs().max()) <= TOL
+                    lo += n
+                model.pointnet2_nocs.set_self_loop_scope("batch")
+                lit = model.pointnet2_forward(data)
+                assert torch.equal(lit["per_point_logits"][:sizes[0]], got["per_point_logits"][:sizes[0]])     # slot 0: the same rule
+                assert not torch.equal(lit["per_point_logits"][sizes[0]:], got["per_point_logits"][sizes[0]:])
+        finally:
+            CP.FUSED_SA = saved
+    with pytest.raises(ValueError):
+        model.pointnet2_nocs.set_self_loop_scope("garment")
+
+
+def test_two_host_threads_two_jobs_two_arithmetics():
+    """reentrant across host threads -- no module-level mutable state on the call path (ops' per-call device is
+    thread-local, the CSR tables sit behind a lock, every thread has its own tail stream).  Two Python threads, each on its own stream,
+    drive a PredictJob with a DIFFERENT Arith on different batches at the same time, several rounds; every result must equal the
+    sequential one bit for bit"""
+    import threading
+    from garmentnets_amd.predict import PredictJob
+    hp = S.default_hparams(grid=32, reduce_method="mean")
+    model = _model(hp, 5)
+    ariths = [AR.Arith.named("f16x2", "f16x2"), AR.Arith.named("fp32", "fp32", sparse_first_conv=False)]
+    batches = []
+    for k in range(2):
+        n = 1800 + 400 * k
+        x, pos, batch = S.synthetic_cloud(2, n, seed=500 + k)
+        batches.append(Batch(sizes=[n] * 2, x=x, pos=pos, batch=batch).to(DEV))
+    w = predict_batch(model, batches[0], volume_size=32, auto_level=True)[0]["wnf_volume"]
+    level = 0.5 * (float(w.min()) + float(w.max()))
+    ref = [predict_batch(model, b, volume_size=32, iso_surface_level=level, arith=a) for b, a in zip(batches, ariths)]
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[0][0]["wnf_volume"], predict_batch(model, batches[0], volume_size=32, iso_surface_level=level, arith=ariths[1])[0]["wnf_volume"])
+    errors, results = [], [None, None]
+    gate = threading.Barrier(2)
+
+    def work(t):
+        try:
+            stream = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    gate.wait(timeout=120)
+                    job = PredictJob(model, batches[t], 32, level, arith=ariths[t])
+                    out = job.finish(host=True)
+                results[t] = out
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, repr(e)))
+            gate.abort()
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    assert not errors, errors
+    for t in range(2):
+        for r, g in zip(ref[t], results[t]):
+            host = to_host(r)
+            assert set(host) == set(g)
+            for k in host:
+                assert host[k].dtype == g[k].dtype and np.array_equal(host[k], g[k], equal_nan=host[k].dtype.kind == "f"), (t, k)
+
+
+def test_predict_main_subset_and_batched_cli(tmp_path):
+    """predict.main as a user runs it on a store: --subset test iterates exactly the data module's seeded test split (static_epoch_seed as
+    the reference's val_dataset), and --batch_size 4 (two batches in flight, per-example self-loop scope) writes, for every sample, what the
+    reference-shaped batch_size 1 loop writes"""
+    from garmentnets_amd import predict as PR
+    from garmentnets_amd.io.dataset import GarmentInputDataset, instance_split
+    rng = np.random.default_rng(9)
+    din = str(tmp_path / "ds.zarr")
+    keys = _write_synthetic_dataset(din, 10, rng)
+    # a fixed level the synthetic checkpoint's WNF volumes straddle (the pipelined path has no auto_level): mid level of sample 0
+    ds0 = GarmentInputDataset(din, num_pc_sample=1500, num_views=3, static_epoch_seed=True, random_rot_range=(-180, 180))
+    w = predict_batch(_model(S.default_hparams(grid=16, reduce_method="max"), 0), GarmentInputDataset.collate([ds0[0]]).to(DEV), volume_size=24, auto_level=True)[0]["wnf_volume"]
+    level = 0.5 * (float(w.min()) + float(w.max()))
+    common = ["--zarr_in", din, "--num_pc_sample", "1500", "--num_views", "3", "--grid", "16", "--volume_size", "24", "--iso_surface_level", repr(level)]
+    PR.main(common + ["--zarr_out", str(tmp_path / "p_test.zarr"), "--subset", "test"])
+    ids = [f"{i:05d}_Dress" for i in range(10)]
+    want = instance_split(ids, (8, 1, 1), 0)["test"]
+    assert len(want) == 1 and sorted(os.listdir(tmp_path / "p_test.zarr" / "samples")) == [keys[int(i)] for i in want]
+    ds = GarmentInputDataset(din, num_pc_sample=1500, num_views=3, static_epoch_seed=True, random_rot_range=(-180, 180))
+    item = ds[int(want[0])]
+    got_pts = _zarr_v2_read(str(tmp_path / "p_test.zarr"), os.path.join("samples", keys[int(want[0])], "point_cloud", "input_points"))
+    assert np.array_equal(got_pts, item["pos"])
+    # batched CLI vs the batch-of-one loop over the same six samples
+    six = common + ["--subset", "all", "--static_epoch_seed", "--num_samples", "6"]
+    PR.main(six + ["--zarr_out", str(tmp_path / "p_b1.zarr"), "--batch_size", "1", "--in_flight", "1"])
+    PR.main(six + ["--zarr_out", str(tmp_path / "p_b4.zarr"), "--batch_size", "4"])
+    n_real = 0
+    for i, key in enumerate(keys[:6]):
+        a = lambda *q: _zarr_v2_read(str(tmp_path / "p_b1.zarr"), os.path.join("samples", key, *q))
+        b = lambda *q: _zarr_v2_read(str(tmp_path / "p_b4.zarr"), os.path.join("samples", key, *q))
+        for k in ("pred_nocs", "pred_nocs_logits", "pred_nocs_confidence", "input_points", "input_rgb", "gt_nocs"):
+            assert np.array_equal(a("point_cloud", k), b("point_cloud", k)), (key, k)
+        for k in ("global_feature", "pred_nocs_grip_point", "pred_global_nocs_grip_point", "gt_nocs_grip_point"):
+            assert np.array_equal(a("misc", k), b("misc", k)), (key, k)
+        va, vb = a("marching_cubes_mesh", "verts"), b("marching_cubes_mesh", "verts")
+        assert va.shape == vb.shape and np.array_equal(a("marching_cubes_mesh", "faces"), b("marching_cubes_mesh", "faces")), key
+        assert np.allclose(va, vb, atol=1e-5, equal_nan=True) and np.allclose(a("marching_cubes_mesh", "warp_field"), b("marching_cubes_mesh", "warp_field"), atol=1e-5, equal_nan=True)
+        assert json.load(open(tmp_path / "p_b4.zarr" / "samples" / key / ".zattrs"))["batch_idx"] == i
+        n_real += int(not np.isnan(va).any())
+    assert n_real >= 3
 
 
 def test_two_process_bench_on_one_gpu():

@@ -301,3 +301,93 @@ def test_polyphase_weights_algebra():
     assert float((got - want).abs().max()) <= 1e-5                                                            # (w0 / wm are stored in fp32)
     assert int((wm != 0).reshape(8 * Cout, -1, 27).any(dim=1).sum(dim=1).max()) == 8                         # 2 x 2 x 2 taps per class
     assert all(bin(int(m) & 0xFF).count("1") in (1, 2, 4, 8) for m in mask.tolist())
+
+
+@pytest.mark.parametrize("si", [0, 1, 2])
+def test_instance_split_matches_reference_golden(golden_dir, si):
+    """the seeded train / val / test instance split behind predict's --subset == the reference data module's prepare_data run on the same
+    sample_id column (tests/golden/make_golden_dataset.py), index for index"""
+    from garmentnets_amd.io import dataset as D
+    g = np.load(os.path.join(golden_dir, "ref_dataset.npz"))
+    *split, seed = g[f"s{si}/params"].tolist()
+    got = D.instance_split(g[f"s{si}/sample_ids"], split, int(seed))
+    for name in ("train", "val", "test"):
+        assert got[name].dtype.kind == "i" and np.array_equal(got[name], g[f"s{si}/{name}"]), name
+    everything = np.sort(np.concatenate([got[n] for n in ("train", "val", "test")]))
+    assert np.array_equal(everything, np.arange(len(g[f"s{si}/sample_ids"])))
+    ids = g[f"s{si}/sample_ids"]
+    assert not (set(ids[got["train"]]) & set(ids[got["test"]])) and not (set(ids[got["val"]]) & set(ids[got["test"]]))   # instances never straddle
+
+
+def _fake_numcodecs():
+    """stand-in for the numcodecs package (not installable offline): get_codec(config) -> an object with encode / decode, like numcodecs'.
+    The 'blosc' here is a marker header + zlib -- enough to prove chunks travel THROUGH the registry codec in both directions"""
+    import types, zlib
+    mod = types.ModuleType("numcodecs")
+    mod.calls = []
+
+    class Codec:
+        def __init__(self, config):
+            self.config = dict(config)
+
+        def encode(self, buf):
+            mod.calls.append(("encode", self.config["id"]))
+            return b"FAKE" + self.config["id"].encode() + b":" + zlib.compress(bytes(buf), 1)
+
+        def decode(self, buf):
+            mod.calls.append(("decode", self.config["id"]))
+            head, body = bytes(buf).split(b":", 1)
+            assert head == b"FAKE" + self.config["id"].encode()
+            return np.frombuffer(zlib.decompress(body), dtype=np.uint8)      # numcodecs returns ndarray-like buffers
+
+    mod.get_codec = lambda config: Codec(config)
+    return mod
+
+
+def test_zarr_store_numcodecs_guard(tmp_path, monkeypatch):
+    """codecs other than zlib: a clear error without numcodecs; with it, chunks are decoded / encoded through numcodecs.get_codec and the
+    prediction store is written with predict.py:77's Blosc(zstd, 6, BITSHUFFLE) config"""
+    import json, sys
+    from garmentnets_amd.io import zarr_store
+    monkeypatch.setitem(sys.modules, "numcodecs", None)                       # import numcodecs -> ImportError
+    assert zarr_store.default_compressor() == ("zlib", 1)
+    root = zarr_store.open_group(str(tmp_path / "a.zarr"))
+    assert "codec_note" in root.attrs
+    with pytest.raises(NotImplementedError, match="numcodecs"):
+        root.array("x", np.arange(10), compressor=zarr_store.REFERENCE_COMPRESSOR)
+    assert not os.path.exists(os.path.join(root.path, "x"))
+    fake = _fake_numcodecs()
+    monkeypatch.setitem(sys.modules, "numcodecs", fake)
+    assert zarr_store.default_compressor() == zarr_store.REFERENCE_COMPRESSOR
+    root2 = zarr_store.open_group(str(tmp_path / "b.zarr"))
+    assert "codec_note" not in root2.attrs
+    data = np.random.default_rng(0).normal(size=(37, 3)).astype(np.float32)
+    g = zarr_store.write_sample(root2.require_group("samples"), "k0", {"verts": data}, {"pred_nocs": data[:5]}, {"global_feature": data[0]})
+    meta = json.load(open(os.path.join(g.path, "marching_cubes_mesh", "verts", ".zarray")))
+    assert meta["compressor"] == {"id": "blosc", "cname": "zstd", "clevel": 6, "shuffle": 2, "blocksize": 0}
+    assert open(os.path.join(g.path, "marching_cubes_mesh", "verts", "0.0"), "rb").read().startswith(b"FAKEblosc:")
+    assert np.array_equal(g["marching_cubes_mesh"]["verts"], data) and ("decode", "blosc") in fake.calls
+    # a chunked input array under another registry codec, as a foreign writer would leave it
+    root2.require_group("in").array("pts", data, chunks=(16, 2), compressor={"id": "lz4", "acceleration": 1})
+    assert np.array_equal(root2["in"]["pts"], data) and ("decode", "lz4") in fake.calls
+    monkeypatch.setitem(sys.modules, "numcodecs", None)
+    with pytest.raises(NotImplementedError, match="blosc"):
+        g["marching_cubes_mesh"]["verts"]
+
+
+def test_dataset_subset_indices(tmp_path):
+    """GarmentInputDataset.subset_indices: the instance split over the store's `sample_id` attrs (views of one garment stay together)"""
+    from garmentnets_amd.io import dataset as D, zarr_store
+    root = zarr_store.open_group(str(tmp_path / "ds.zarr"))
+    root.require_group("summary").array("cloth_aabb_union", np.zeros((2, 3), dtype=np.float32))
+    ids = [f"{i // 2:03d}_Dress" for i in range(40)]                         # 20 instances x 2 samples
+    for k, sid in enumerate(ids):
+        root.require_group("samples").require_group(f"{k:05d}").put_attrs({"sample_id": sid, "scale": 1.0, "grip_vertex_idx": 0})
+    ds = D.GarmentInputDataset(str(tmp_path / "ds.zarr"))
+    tr, va, te = (ds.subset_indices(n) for n in ("train", "val", "test"))
+    assert (len(tr), len(va), len(te)) == (32, 4, 4)
+    want = D.instance_split(ids, (8, 1, 1), 0)
+    assert all(np.array_equal(a, want[n]) for a, n in ((tr, "train"), (va, "val"), (te, "test")))
+    assert all(i ^ 1 in set(te.tolist()) for i in te.tolist())               # both samples of an instance
+    with pytest.raises(KeyError):
+        ds.subset_indices("everything")
