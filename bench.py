@@ -19,13 +19,22 @@ timings (RCCL).  Rank 0 prints ONE JSON line:
                         metric as SURVEY.md 8d words it
   roofline              dominant kernel by time: launches bracketed with HIP events on the launch stream during the timed steps,
                         labelled with the kernel variant the C ABI reports having launched (gn_last_kernel), achieved = algorithmic
-                        FLOPs (54*Cin*Cout per voxel) / time; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
-                        of this same command (profiles/, `traffic_source`), only when the workload is the profiled one
+                        FLOPs (54*Cin*Cout per voxel) / time.  The kernel runs at the socket's power cap, so the line carries the
+                        evidence: `sclk_mhz` / `socket_power_w` sampled from the GPU's hwmon nodes DURING the headline pass and
+                        `frac_at_2400mhz` = frac x 2400 / sclk (what the same issue rate would be at the guide's peak clock).
+                        `traffic` = HBM bytes per launch measured IN THIS RUN: two short rocprofv3 child passes of the same step on
+                        this box (--pmc FETCH_SIZE, --pmc WRITE_SIZE, gfx950-corrected as tools/pmc_summary.py documents), or null
+                        when rocprofv3 is not usable -- never a number from another box's committed profile
   occupancy_aware       the same K steps with the library's default occupancy-aware first two UNet convolutions (exact: bit-identical outputs,
                         tests/test_gpu_parity.py::test_sparse_first_conv_is_bit_identical_to_dense).  The HEADLINE value is measured with
-                        that path switched OFF: every tile goes through the matrix cores and the number does not depend on where the points fall
-  literal_affine        the same K steps with Arith.affine_in_weights off (the GroupNorm shift inside the MFMA operand of the first two encoder
-                        convolutions): the same-box A/B of the power lever of DESIGN.md 4.3
+                        that path switched OFF: every tile goes through the matrix cores.  The MAC count then does not depend on where
+                        the points fall -- the SPEED still does: with Arith.affine_in_weights (on for the headline) the MFMA operand of
+                        the first two encoder convolutions (73 % of the dominant kernel's FLOPs) is exactly zero outside the occupied
+                        cells' neighbourhood (>= 99 % of the voxels of this input); zero operands draw less power, the clock rises
+                        under the cap and `roofline.frac` counts those MACs at full value.  Hence:
+  literal_affine        the same K steps with Arith.affine_in_weights off (the GroupNorm shift inside the MFMA operand: every voxel
+                        non-zero) -- the occupancy-INDEPENDENT figure, with its own roofline (`literal_affine.roofline`); quote it
+                        next to the headline
   hbm_members           the HBM-bound members of the path (zero-fill, scatter, max-pool, lattice sampler, GGM, MC33 stages): HIP-event time,
                         algorithmic bytes, fraction of 8 TB/s
   validation            untimed: a batch of IDENTICAL garments (PointConv self-loop quirk off) must give the same WNF and mesh in the
@@ -89,6 +98,11 @@ def parse():
     ap.add_argument("--no-host-io-pass", action="store_true", help="skip the timed pass that includes H2D of the clouds / D2H of the meshes")
     ap.add_argument("--no-occupancy-pass", action="store_true", help="skip the timed passes with the occupancy-aware first convolution")
     ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic on this box")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin this rank to its GPU's NUMA-local cores")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--n1-value", type=float, default=None, help="garments/s of the N=1 run of the same sweep (tools/run_scale.sh passes it): the line "
+                                                                   "then carries scaling_vs_n1 = value / (N x n1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-garments", type=int, default=1)
     a = ap.parse_args()
@@ -282,22 +296,53 @@ class HbmMembers:
         return out
 
 
-def measured_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs
-    of THIS command, corrected as profiles/*_fetch_calibration.txt documents; tools/pmc_summary.py) -- only quoted when the workload is
-    the one that was profiled.  -> (bytes or None, source file or None)"""
-    if (args.workload, args.batch, args.points, args.grid, args.reduce, args.volume_size, args.conv_mode, args.input) != ("full", 16, 6000, 128, "mean", 128, "f16x2", "planted"):
-        return None, None
-    for name in ("r03_hbm_traffic.json",):
-        path = os.path.join(REPO, "profiles", name)
-        if os.path.exists(path):
-            k = json.load(open(path))["kernels"].get(kernel)
-            if k is not None:
-                return k["hbm_bytes"], "profiles/" + name + " (committed PMC passes of this command, not this run)"
-    return None, None
+def pmc_child(args, model, data, step):
+    """what the rocprofv3 child passes run: one warm-up and one measured step of the headline arithmetic, nothing else"""
+    step()
+    torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
 
 
-def conv_roofline(args, groups, conv_mode):
+def measure_traffic(args):
+    """HBM bytes per launch of every kernel of one headline step, measured on THIS box in THIS run: two rocprofv3 child passes of
+    `bench.py --pmc-child` (same workload arguments; --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md's HBM section prescribes; gfx950 FETCH_SIZE correction per kernel: tools/pmc_summary.py).
+    -> ({kernel: {...bytes per launch...}}, note) or (None, why not)"""
+    import shutil
+    import subprocess
+    import tempfile
+    torch.cuda.empty_cache()                 # the child allocates the same working set on this GPU
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import pmc_summary
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch), "--points", str(args.points),
+             "--grid", str(args.grid), "--reduce", args.reduce, "--volume-size", str(args.volume_size), "--input", args.input,
+             "--conv-mode", args.conv_mode, "--decode-mode", args.decode_mode]
+    env = dict(os.environ, TMPDIR="/tmp", GARMENTNETS_PREFETCH_ZERO="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(prefix="gn_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "pmc", "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} child pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} child pass failed (rc {r.returncode}): " + r.stdout.decode(errors="replace")[-300:]
+        try:
+            summ = pmc_summary.summarise(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"))
+        except Exception as e:      # noqa: BLE001
+            return None, f"could not read the counter CSVs: {e!r}"
+    return summ["kernels"], (f"this run, this box: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of one headline step "
+                             f"({time.time() - t0:.0f} s); FETCH_SIZE x per-kernel gfx950 factor (tools/pmc_summary.py), WRITE_SIZE as reported")
+
+
+def conv_roofline(args, groups, conv_mode, hw=None, traffic=None):
+    """hw: HwmonSampler.summary() of the pass; traffic: (measure_traffic's kernel table, note) of this run"""
     key = max(groups, key=lambda k: groups[k]["ms"])
     g = groups[key]
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12          # algorithmic (fp32) FLOPs: 54*Cin*Cout per voxel
@@ -308,15 +353,28 @@ def conv_roofline(args, groups, conv_mode):
         peak = PEAK_16BIT_MFMA_TFLOPS / n
         peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} matrix-core products per algorithmic fp32 product "
                      f"({conv_mode}); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
-    traffic, src = measured_traffic(args, key) if conv_mode == args.conv_mode else (None, None)
-    return {"bound": "mfma", "kernel": key, "kernel_label": "reported by the C ABI (gn_last_kernel) after each launch",
+    tr, src, tr_detail = None, None, None
+    if traffic is not None:
+        table, src = traffic
+        if table is not None and key in table:
+            tr, tr_detail = table[key]["hbm_bytes"], table[key]
+    out = {"bound": "mfma", "kernel": key, "kernel_label": "reported by the C ABI (gn_last_kernel) after each launch",
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
-            "traffic": traffic, "traffic_source": src,
+            "traffic": tr, "traffic_source": src, "traffic_detail": tr_detail,
             "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["work"] / g["n"],
             "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
             "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["work"] / (v["ms"] * 1e-3) / 1e12}
+            "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["work"] / (v["ms"] * 1e-3) / 1e12,
+                                       "frac": v["work"] / (v["ms"] * 1e-3) / 1e12 / peak}
                                    for k, v in groups.items()}}
+    if hw is not None:
+        sclk = hw.get("sclk_mhz")
+        out.update(sclk_mhz=sclk, socket_power_w=hw.get("socket_power_w"), power_cap_w=hw.get("power_cap_w"),
+                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None,
+                   clock_note="sclk / socket power: mean of the GPU's hwmon nodes sampled every 50 ms during this pass (all kernels of the step, "
+                              "not the dominant one alone); the peak assumes 2400 MHz, frac_at_2400mhz = frac x 2400 / sclk is the matrix-core "
+                              "issue rate the kernel sustains per clock; busy counters: profiles/", hwmon=hw)
+    return out
 
 
 def points_roofline(groups):
@@ -464,6 +522,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     parallel.init(backend=backend, device=dev)     # "nccl" is RCCL on ROCm; no-op for one process
+    # one host process per GPU: keep each rank's host side (Python, mesh slicing, pinned D2H staging) on its GPU's NUMA-local cores
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    full_mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if args.no_affinity or world == 1:
+        affinity = {"pinned": False, "why_not": "--no-affinity" if args.no_affinity else "single rank: nothing shares the host"}
+    else:
+        affinity = parallel.pin_rank(local_rank, local_world, dev_index)
     metrics_dev = dev if backend == "nccl" else "cpu"
 
     from garmentnets_amd import ops
@@ -526,19 +591,29 @@ def main():
             res = prev.finish(host=fn is step_host_io)
         return res
 
-    def timed(fn, steps, warmup):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from power_trace import HwmonSampler
+    hw_passes = {}
+
+    def timed(fn, steps, warmup, hw_name=None):
         run_steps(fn, warmup)
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
         timer.reset()
         timer.enabled = True
+        sampler = HwmonSampler(dev_index) if (hw_name and rank == 0) else None
+        if sampler is not None:
+            sampler.__enter__()
         t0 = time.perf_counter()
         res = run_steps(fn, steps)
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if sampler is not None:
+            sampler.__exit__(None, None, None)
+            hw_passes[hw_name] = sampler.summary()
         timer.enabled = False
         return dt, res, timer.summary()
 
@@ -548,8 +623,12 @@ def main():
         if any(bool(torch.isnan(r["verts"]).any()) for r in probe_res):
             auto_level[0] = True
         del probe_res
+    if args.pmc_child:                                # under rocprofv3 --pmc (measure_traffic): the headline step, twice, and out
+        pmc_child(args, model, data, step)
+        return
     pipelined[0] = args.workload == "full" and args.pipeline_depth == 2 and not auto_level[0]
-    dt, res, groups = timed(step, args.steps, max(2, args.warmup - 1) if pipelined[0] else max(0, args.warmup - (1 if args.workload == "full" else 0)))
+    dt, res, groups = timed(step, args.steps, max(2, args.warmup - 1) if pipelined[0] else max(0, args.warmup - (1 if args.workload == "full" else 0)),
+                            hw_name="headline")
     verts_total = None
     checksums = []                                   # per local garment: fp64 sum of its WNF volume (full) / logits (pointnet2), last timed step
     probe = None                                     # slot 0 of the timed result, kept for the oracle check of the cpu_baseline leg
@@ -574,7 +653,7 @@ def main():
     strict = None
     if not args.no_strict_pass and (args.conv_mode, args.decode_mode) != ("fp32", "fp32") and args.workload == "full":
         model.arith = headline.strict_fp32()
-        dt_s, res_s, groups_s = timed(step, args.steps, 1)
+        dt_s, res_s, groups_s = timed(step, args.steps, 1, hw_name="strict_fp32")
         del res_s
         strict = (dt_s, groups_s)
         model.arith = headline
@@ -602,10 +681,11 @@ def main():
             vin = model.volume_agg(model.pointnet2_forward(data)["nocs_data"])
             probe["occ0"] = (vin[0] != 0).any(dim=0).cpu()
             del vin
+    groups_l = None
     literal = None          # the same steps with the GroupNorm shift inside the MFMA operand (Arith.affine_in_weights off): the A/B of DESIGN.md 4.3 on THIS box
     if not args.no_occupancy_pass and args.workload == "full" and args.conv_mode == "f16x2" and headline.affine_in_weights:
         model.arith = headline.replace(affine_in_weights=False)
-        literal, _, _ = timed(step, args.steps, 1)
+        literal, _, groups_l = timed(step, args.steps, 1, hw_name="literal_affine")
         model.arith = headline
 
     # per-stage HIP-event times of ONE extra, untimed step; the stages are the reference's own stage methods.  The same
@@ -694,7 +774,8 @@ def main():
             workload = (f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, {args.grid}^3 feature volume ({args.reduce}), "
                         f"{args.volume_size}^3 WNF + GGM + MC33 + surface decode; input: {input_note}"
                         + (f" ({occupancy['occupied_cells_per_garment']:.0f} occupied cells per garment)" if occupancy else ""))
-            roofline = conv_roofline(args, groups, args.conv_mode)
+            traffic = (None, "--no-pmc") if args.no_pmc else measure_traffic(args)
+            roofline = conv_roofline(args, groups, args.conv_mode, hw_passes.get("headline"), traffic)
         line = {
             "metric": metric, "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -715,6 +796,10 @@ def main():
             "pipeline_depth": 2 if pipelined[0] else 1,
             "rccl_ranks_seen": len(per_rank),
             "dist_backend": backend if world > 1 else None,
+            "per_rank": {"seconds": [r[1] for r in per_rank], "garments_per_s": [r[0] / r[1] for r in per_rank],
+                         "slowest_over_fastest": max(r[1] for r in per_rank) / min(r[1] for r in per_rank),
+                         "host_affinity_rank0": affinity},
+            "scaling_vs_n1": (garments / tmax) / (world * args.n1_value) if args.n1_value else None,
             "garment_checksums": [c for r in all_sums for c in r],      # global garment order (rank-major): fp64 sum of each result
             "stages_ms": stages_ms,
             "roofline": roofline,
@@ -731,7 +816,7 @@ def main():
             ts = max(r[2] for r in per_rank)
             line["strict_fp32"] = {"value": garments / ts, "unit": "garments/s", "ms_per_step": 1e3 * ts / args.steps, "steps": args.steps,
                                    "dtype": "f32 (v_mfma_f32_32x32x2_f32 convs + fp32 decoder MLPs: --conv-mode fp32 --decode-mode fp32)",
-                                   "roofline": conv_roofline(args, strict[1], "fp32")}
+                                   "roofline": conv_roofline(args, strict[1], "fp32", hw_passes.get("strict_fp32"))}
         if hostio:
             th = max(r[3] for r in per_rank)
             line["with_host_io"] = {"value": garments / th, "unit": "garments/s", "ms_per_step": 1e3 * th / args.steps, "steps": args.steps,
@@ -751,10 +836,14 @@ def main():
                 "value": garments / tl, "unit": "garments/s", "ms_per_step": 1e3 * tl / args.steps,
                 "what": "the same K steps with Arith.affine_in_weights off: the GroupNorm shift inside the MFMA operand of the first two encoder convolutions "
                         "(every voxel of the >= 99.7 % empty volume non-zero) instead of in per-sample weights + a bias table -- the same MACs through the same "
-                        "kernels; the difference is clock under the socket's power cap (DESIGN.md 4.3)"}
+                        "kernels; the difference is clock under the socket's power cap (DESIGN.md 4.3).  This is the occupancy-INDEPENDENT "
+                        "figure: quote it next to the headline",
+                "roofline": conv_roofline(args, groups_l, args.conv_mode, hw_passes.get("literal_affine"))}
         if validation is not None:
             line["validation"] = validation
         if world == 1 and not args.no_cpu_baseline:
+            if full_mask is not None:
+                os.sched_setaffinity(0, full_mask)          # the CPU baseline may use every core of the host
             line["cpu_baseline"], check = cpu_baseline(args, hp, sd, shard, probe)
             if check is not None:
                 line["oracle_check"] = check

@@ -44,6 +44,67 @@ def shard_batch(global_batch, n_points, seed, rank, world, colour="uniform"):
     return Batch(sizes=[n_points] * (hi - lo), x=x, pos=pos, batch=batch), (lo, hi)
 
 
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def local_cpus_of_device(index):
+    """host cores on the NUMA node of HIP device `index` (sysfs local_cpulist of its PCI function) or None when sysfs does not tell"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        import glob
+        for d in glob.glob(f"/sys/bus/pci/devices/{bdf}.*"):
+            cpus = _parse_cpulist(open(os.path.join(d, "local_cpulist")).read())
+            if cpus:
+                return cpus
+    except Exception:
+        pass
+    return None
+
+
+def plan_affinity(local_rank, local_world, device_of_rank, cpus_of_device, allowed):
+    """pure planning (tested on CPU): the cores rank `local_rank` of `local_world` local ranks should run on.  Every rank takes its
+    device's NUMA-local cores (restricted to `allowed`, the process's current mask); ranks whose devices share a core list split it into
+    equal contiguous slices in rank order, so that eight host-side tails (mesh slicing, pinned D2H, Python) never pile onto one node's
+    cores.  -> sorted list of cores (never empty)"""
+    allowed = sorted(allowed)
+    lists = []
+    for r in range(local_world):
+        cpus = cpus_of_device(device_of_rank(r))
+        cpus = [c for c in (cpus or allowed) if c in set(allowed)] or allowed
+        lists.append(tuple(cpus))
+    mine = lists[local_rank]
+    peers = [r for r in range(local_world) if lists[r] == mine]
+    k, n = peers.index(local_rank), len(peers)
+    per = max(1, len(mine) // n)
+    sl = list(mine[k * per:(k + 1) * per]) if k * per < len(mine) else [mine[k % len(mine)]]
+    return sl or list(mine)
+
+
+def pin_rank(local_rank, local_world, device_index, max_threads=8):
+    """bind this process to its GPU's NUMA-local share of the host cores (plan_affinity) and size torch's CPU thread pool to it.
+    -> description dict for the bench line; never raises (a container without sched_setaffinity keeps its mask)"""
+    info = {"pinned": False}
+    try:
+        allowed = os.sched_getaffinity(0)
+        ndev = max(1, torch.cuda.device_count())
+        cores = plan_affinity(local_rank, local_world, lambda r: r % ndev, local_cpus_of_device, allowed)
+        os.sched_setaffinity(0, cores)
+        torch.set_num_threads(max(1, min(max_threads, len(cores))))
+        info.update(pinned=True, cores=len(cores), first_core=cores[0], last_core=cores[-1], torch_threads=torch.get_num_threads(),
+                    numa_local=local_cpus_of_device(device_index) is not None)
+    except Exception as e:      # noqa: BLE001
+        info["why_not"] = repr(e)
+    return info
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

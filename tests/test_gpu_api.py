@@ -602,7 +602,7 @@ def test_predict_main_subset_and_batched_cli(tmp_path):
     assert n_real >= 3
 
 
-def test_two_process_bench_on_one_gpu():
+def _two_rank_bench(backend):
     """the N > 1 path of bench.py as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU: two
     ranks share cuda:0 and exchange their metrics over gloo (GARMENTNETS_DIST_BACKEND=gloo; RCCL needs one device per rank).  The line
     must see both ranks, the global batch must be the two shards, and the per-garment result checksums, in rank order, must equal what
@@ -615,17 +615,19 @@ def test_two_process_bench_on_one_gpu():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, GARMENTNETS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, GARMENTNETS_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", str(cfg["batch"]), "--points", str(cfg["points"]),
            "--grid", str(cfg["grid"]), "--volume-size", str(cfg["Q"]), "--no-strict-pass", "--no-host-io-pass", "--no-occupancy-pass", "--no-in-flight-pass",
-           "--no-validate", "--no-cpu-baseline"]
+           "--no-validate", "--no-cpu-baseline", "--no-pmc"]
     out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints, rank 1 does not
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["dist_backend"] == "gloo"
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["dist_backend"] == backend
+    assert len(line["per_rank"]["seconds"]) == 2 and all(t > 0 for t in line["per_rank"]["seconds"]) and line["per_rank"]["slowest_over_fastest"] >= 1.0
+    assert line["per_rank"]["host_affinity_rank0"]["pinned"], line["per_rank"]
     assert line["config"]["global_batch"] == 4 and line["config"]["batch_per_gpu"] == 2 and line["value"] > 0
     assert abs(line["value"] - 4 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-6 * line["value"]
     sums = line["garment_checksums"]
@@ -636,9 +638,22 @@ def test_two_process_bench_on_one_gpu():
         assert (lo, hi) == (2 * r, 2 * r + 2)
         model = ConvImplicitWNFPipeline(**hp)
         model.load_state_dict(sd)
-        model = model.to(DEV).eval().requires_grad_(False)
+        dev_r = DEV if backend == "gloo" else f"cuda:{r}"          # nccl: rank r computed on device r -- so does the reference run here
+        model = model.to(dev_r).eval().requires_grad_(False)
         model.arith = model.arith.replace(sparse_first_conv=False)
-        res = predict_batch(model, shard.to(DEV), volume_size=cfg["Q"], iso_surface_level=0.5, auto_level=line["config"]["iso_level"] != 0.5)
+        res = predict_batch(model, shard.to(dev_r), volume_size=cfg["Q"], iso_surface_level=0.5, auto_level=line["config"]["iso_level"] != 0.5)
         want += [float(x["wnf_volume"].double().sum()) for x in res]
     assert np.allclose(sums, want, rtol=1e-6, atol=1e-6), (sums, want)
     assert len(set(round(v, 3) for v in sums)) == 4                 # four different garments
+
+
+def test_two_process_bench_on_one_gpu():
+    """two ranks share cuda:0 and exchange their metrics over gloo (RCCL needs one device per rank) -- runs on the 1-GPU box"""
+    _two_rank_bench("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs the day the box has two GPUs")
+def test_two_process_bench_over_rccl():
+    """the same launch with the production backend: init_process_group("nccl", device_id=cuda:LOCAL_RANK), rank 1's whole data path on
+    device ordinal 1 (gn_stream's device binding), the metrics all-gather over RCCL; checksums against in-process runs on the same devices"""
+    _two_rank_bench("nccl")

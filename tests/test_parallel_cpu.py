@@ -96,3 +96,26 @@ def test_two_rank_global_batch_is_the_concatenation_of_the_shards():
     assert g0 == g1 and len(g0) == 2                                   # every rank saw both ranks' records
     got = g0[0][1:1 + int(g0[0][0])] + g0[1][1:1 + int(g0[1][0])]
     assert got == want
+
+
+def test_plan_affinity_splits_numa_local_cores_between_the_ranks_that_share_them():
+    """bench.py pins every rank to its GPU's NUMA-local cores; ranks whose GPUs hang off the same node split that node's cores (8 ranks on a
+    2-socket host: 4 + 4), a container mask is respected, and unknown topology falls back to an even split of the allowed cores"""
+    from garmentnets_amd import parallel
+    node = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    cpus_of = lambda d: node[d // 4]                      # GPUs 0-3 on socket 0, 4-7 on socket 1
+    allowed = set(range(128))
+    plans = [parallel.plan_affinity(r, 8, lambda r: r, cpus_of, allowed) for r in range(8)]
+    assert all(len(p) == 16 for p in plans)
+    assert plans[0] == list(range(0, 16)) and plans[3] == list(range(48, 64)) and plans[4] == list(range(64, 80))
+    assert len(set(c for p in plans for c in p)) == 128      # disjoint cover
+    # two ranks sharing ONE device (the gloo test mode) share its node: halves
+    two = [parallel.plan_affinity(r, 2, lambda r: 0, cpus_of, allowed) for r in range(2)]
+    assert two[0] == list(range(0, 32)) and two[1] == list(range(32, 64))
+    # container mask: only cores 10..19 allowed -> NUMA list intersected
+    masked = parallel.plan_affinity(1, 2, lambda r: r, lambda d: node[0], set(range(10, 20)))
+    assert masked == list(range(15, 20))
+    # sysfs silent -> even split of the allowed cores; more ranks than cores -> still one core each
+    assert parallel.plan_affinity(1, 4, lambda r: r, lambda d: None, set(range(8))) == [2, 3]
+    assert parallel.plan_affinity(5, 8, lambda r: r, lambda d: None, {0, 1, 2}) in ([0], [1], [2])
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

@@ -33,19 +33,25 @@ import glob
 
 
 def find(d):
-    c = glob.glob(d + "/*counter_collection.csv")
+    c = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     return c[0] if c else d + "/pmc_counter_collection.csv"
 
 
-fetch = load(find(sys.argv[1]))
-write = load(find(sys.argv[2]))
-out = {"units": "bytes per launch (average over the run)", "fetch_correction": "2.0 unless listed per kernel (calibrated)", "kernels": {}}
-for k in sorted(fetch, key=lambda k: -fetch[k][1]):
-    if fetch[k][1] < 1024:
-        continue
-    n = fetch[k][0]
-    fac = FETCH_FACTOR.get(k, 2.0)
-    f = fac * fetch[k][1] * 1024 / n
-    w = write.get(k, [n, 0.0])[1] * 1024 / n
-    out["kernels"][k] = {"launches": n, "fetch_factor": fac, "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
-json.dump(out, sys.stdout, indent=1)
+def summarise(fetch_dir, write_dir):
+    """-> {"kernels": {name: {launches, fetch_factor, fetch_bytes, write_bytes, hbm_bytes}}} (bytes per launch, averaged over the run)"""
+    fetch = load(find(fetch_dir))
+    write = load(find(write_dir))
+    out = {"units": "bytes per launch (average over the run)", "fetch_correction": "2.0 unless listed per kernel (calibrated)", "kernels": {}}
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        if fetch[k][1] < 1024:
+            continue
+        n = fetch[k][0]
+        fac = FETCH_FACTOR.get(k, 2.0)
+        f = fac * fetch[k][1] * 1024 / n
+        w = write.get(k, [n, 0.0])[1] * 1024 / n
+        out["kernels"][k] = {"launches": n, "fetch_factor": fac, "fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
+    return out
+
+
+if __name__ == "__main__":
+    json.dump(summarise(sys.argv[1], sys.argv[2]), sys.stdout, indent=1)

@@ -72,6 +72,81 @@ def hip_card():
     return None
 
 
+def card_of_device(index=0):
+    """sysfs (card name, device dir, hwmon dir) of torch's HIP device `index` IN THIS PROCESS (PCI bus id -> /sys/bus/pci/devices/*/drm/cardN),
+    or None when the nodes are not visible"""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        for d in glob.glob(f"/sys/bus/pci/devices/{bdf}.*/drm/card[0-9]*"):
+            name = os.path.basename(d)
+            for c in cards():
+                if c[0] == name:
+                    return c
+    except Exception:
+        pass
+    return None
+
+
+class HwmonSampler:
+    """background sampler of ONE GPU's socket power and shader clock (amdgpu hwmon: power1_average | power1_input, freq1_input) for the
+    duration of a `with` block: bench.py brackets its headline pass with it, so that the roofline fraction of a power-capped kernel comes
+    with the clock it was measured at.  .summary() -> dict (None values when the nodes are unreadable)"""
+
+    def __init__(self, device_index=0, period_s=0.05):
+        self.card, self.period, self.rows = card_of_device(device_index), period_s, []
+        self._stop, self._th = threading.Event(), None
+
+    def _read(self):
+        _, dev, hw = self.card
+        def num(path, scale):
+            try:
+                return float(open(path).read().split()[0]) * scale
+            except Exception:
+                return None
+        p = num(os.path.join(hw, "power1_average"), 1e-6)
+        if p is None:
+            p = num(os.path.join(hw, "power1_input"), 1e-6)
+        return p, num(os.path.join(hw, "freq1_input"), 1e-6), num(os.path.join(hw, "freq2_input"), 1e-6)
+
+    def __enter__(self):
+        self.rows = []
+        if self.card is not None:
+            self._stop.clear()
+
+            def loop():
+                while not self._stop.is_set():
+                    self.rows.append(self._read())
+                    self._stop.wait(self.period)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th is not None:
+            self._th.join(timeout=2)
+        return False
+
+    def summary(self):
+        def stat(i):
+            v = [r[i] for r in self.rows if r[i] is not None and r[i] > 0]
+            return (sum(v) / len(v), min(v), max(v)) if v else (None, None, None)
+        (p, pmin, pmax), (f, fmin, fmax), (m, _, _) = stat(0), stat(1), stat(2)
+        cap = None
+        if self.card is not None:
+            try:
+                cap = float(open(os.path.join(self.card[2], "power1_cap")).read().split()[0]) * 1e-6
+            except Exception:
+                pass
+        return {"samples": len(self.rows), "period_s": self.period, "card": self.card[0] if self.card else None,
+                "socket_power_w": p, "socket_power_w_min_max": [pmin, pmax], "power_cap_w": cap,
+                "sclk_mhz": f, "sclk_mhz_min_max": [fmin, fmax], "mclk_mhz": m,
+                "source": "amdgpu hwmon (power1_average|power1_input, freq1_input) of the GPU this process computes on" if self.card else
+                          "amdgpu hwmon nodes of this GPU are not readable from the process"}
+
+
 def main():
     out, cmd = sys.argv[1], sys.argv[2:]
     mine = hip_card()
