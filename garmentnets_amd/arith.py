@@ -57,6 +57,11 @@ class Arith:
             raise ValueError(f"conv_mode={self.conv_mode!r}")
         if self.decode_mode not in DECODE_MODES:
             raise ValueError(f"decode_mode={self.decode_mode!r}")
+        if self.conv_mode == SPLIT_BF16X2:
+            import warnings
+            warnings.warn("garmentnets_amd: conv_mode bf16x2 is a PREVIEW arithmetic -- it does not guarantee the 1e-4 WNF tolerance (0.9-1.2e-4 "
+                          "observed on the G=32 goldens) and a finite over-tolerance result is not caught by predict's NaN fallback; use f16x2 "
+                          "(default), bf16x3 or fp32 for results held to the reference's tolerance", RuntimeWarning, stacklevel=3)
 
     @classmethod
     def named(cls, conv="f16x2", decode="f16x2", **kw):

@@ -173,7 +173,11 @@ def largest_connected_component(mc_faces, num_verts):
 def remove_holes(mc_verts, mc_faces, pred_value, value_threshold, extra_verts=()):
     """the reference's hole removal, eval.py:529-548: vertices whose predicted on-surface value exceeds the threshold, the faces made of them
     only (delete_invalid_verts), then the largest connected component of what is left (delete_invalid_verts again).  extra_verts: further
-    per-vertex arrays carried through both compactions (eval.py's pred_mc_sim_verts).  -> (verts, faces, [extras...]) of the component."""
+    per-vertex arrays carried through both compactions (eval.py's pred_mc_sim_verts).  -> (verts, faces, [extras...]) of the component.
+
+    Empty result: when no face survives the threshold there is no component to pick -- the reference's np.argmax(cc_sizes) raises
+    ``ValueError: attempt to get argmax of an empty sequence`` there (eval.py:540), and so does this function, with that message; callers that
+    prefer an empty mesh catch ValueError."""
     on_surface = pred_value > value_threshold
     v1, f1 = delete_invalid_verts(mc_verts, mc_faces, on_surface)
     e1 = [delete_invalid_verts(e, mc_faces, on_surface)[0] for e in extra_verts]

@@ -99,7 +99,14 @@ extern "C" int gn_mesh_largest_component(const int32_t *faces, int64_t F, int64_
     GN_REQUIRE(info != nullptr, "gn_mesh_largest_component: info (device int64[4]) is required");
     hipStream_t st = gn_stream(stream);
     GN_HIP(hipMemsetAsync(info, 0, 4 * sizeof(int64_t), st), "gn_mesh_largest_component");
-    if (V == 0) return GN_OK;
+    if (V == 0) {
+        if (F > 0) {   // faces over an empty vertex set: every index is out of range (gn_mesh_compact reports the same case the same way)
+            const int64_t one = 1;
+            GN_HIP(hipMemcpyAsync(info + 3, &one, sizeof(one), hipMemcpyHostToDevice, st), "gn_mesh_largest_component");
+            GN_HIP(hipStreamSynchronize(st), "gn_mesh_largest_component");   // `one` lives on this frame
+        }
+        return GN_OK;
+    }
     GN_REQUIRE((faces || F == 0) && mask && ws, "gn_mesh_largest_component: null pointer");
     GN_REQUIRE(ws_bytes >= gn_mesh_largest_component_workspace_bytes(V), "gn_mesh_largest_component: workspace too small");
     int *parent = (int *)ws, *count = parent + V;

@@ -1042,8 +1042,12 @@ __global__ __launch_bounds__(1024) void occ_compact_kernel(const unsigned char *
 // epilogue statistics.  One 256-thread workgroup per (y, x) COLUMN of tiles and sample: it walks the column's tiles (at the conv kernel's tile
 // granularity), skips the active ones and accumulates the statistics of the rest in registers -- one reduction and one set of atomics per
 // column instead of per tile.  A thread owns one channel quad and every (256 / quads)-th voxel: float4 stores, 512 contiguous bytes per voxel
-// for 128 channels.  Tiles away from the faces hold ONE value per channel: their statistics are count * v (the same fp64 value the voxel-by-
-// voxel sum gives: a thread adds at most 2^6 equal 24- / 48-bit terms).  HBM-bound.
+// for 128 channels.  Tiles away from the faces hold ONE value per channel: their statistics are taken in closed form, count * v and
+// count * v^2 in fp64.  count * v is exact (24-bit v, count <= 2^6 per thread); count * v^2 is NOT always (a 48-bit square times up to
+// 2^6 needs 54 bits), and the fp64 atomics that merge workgroups land in whatever order the hardware schedules them.  The statistics of an
+// occupancy-aware launch therefore agree with the dense launch's to fp64 rounding (~1e-16 relative), not bit for bit -- what IS bit-identical
+// to the dense launch is this layer's OUTPUT (tests/test_gpu_parity.py::test_sparse_first_conv_is_bit_identical_to_dense compares the
+// conv output; a following layer's fp32 GroupNorm coefficients can differ by an ulp).  HBM-bound.
 __global__ __launch_bounds__(256) void conv_fill_inactive_kernel(SplitArgs p, const unsigned char *__restrict__ flags, int pair) {
     const int TZ = SP_TZ * pair, tz4 = (p.D + SP_TZ - 1) / SP_TZ, tiles_z = (p.D + TZ - 1) / TZ;
     const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x, b = blockIdx.y;
@@ -1151,6 +1155,8 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     // bit-identical across all variants anyway: per element the products arrive in the same order; the border-class constants of an
     // occupancy-aware layer may therefore come from a launch over a tiny volume, whichever variant that takes.)
     GN_REQUIRE((tile_active == nullptr) == (kconst == nullptr), "gn_conv3d_gcr_split: tile_active and kconst come together");
+    GN_REQUIRE(!(tile_active && partial), "gn_conv3d_gcr_split: the occupancy-aware launch cannot take a polyphase partial (inactive tiles are "
+                                          "filled with the border-class constants alone: the partial would be dropped there)");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
     // x-strip variant for the column blocks the 64- and 128-wide kernels do not take (two-plane modes, one full-resolution source)

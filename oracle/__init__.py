@@ -38,7 +38,10 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libgn_oracle.so")
-        if not os.path.exists(so):
+        override = os.environ.get("GN_ORACLE_LIB")         # tests/test_oracle_asan.py: the sanitizer build of the same source (make -C oracle asan)
+        if override:
+            so = override
+        elif not os.path.exists(so):
             build()
         L = ctypes.CDLL(so)
         vp, i64, f64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int

@@ -4,6 +4,7 @@ Bit-exact for index / integer results (fps order, ball-query tables, cell indice
 vertex ids, GGM); fp32 results within the tolerance written next to each check (north_star: 1e-4 on WNF / NOCS).
 """
 import hashlib
+import warnings
 import os
 
 import numpy as np
@@ -223,6 +224,26 @@ def test_hip_graph_replay_is_bit_identical():
         g(Batch(sizes=[900], x=d0.x[:900], pos=d0.pos[:900], batch=d0.batch[:900]))
 
 
+def test_bf16x2_preview_mode_warns_and_is_tracked_against_the_contract(golden_dir):
+    """the PREVIEW arithmetic announces itself (RuntimeWarning at selection), and its distance to the 1e-4 contract stays visible: an
+    xfail (non-strict) that turns into an XPASS the day the mode meets the tolerance"""
+    with pytest.warns(RuntimeWarning, match="PREVIEW"):
+        ar = AR.Arith.named("bf16x2")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        AR.Arith.named("f16x2"), AR.Arith.named("bf16x3"), AR.Arith.named("fp32")            # the contract-grade modes are silent
+    g = np.load(os.path.join(golden_dir, "ref_dress_g32.npz"))
+    B, n, G, Q, seed, stride = [int(v) for v in g["meta"]]
+    model = _model(S.default_hparams(grid=G, reduce_method=str(g["reduce_method"])), seed)
+    x, pos, batch = S.synthetic_cloud(B, n, seed)
+    model.arith = ar
+    u3 = model.unet3d_forward(model.pointnet2_forward(Batch(sizes=[n] * B, x=x, pos=pos, batch=batch).to(DEV)))
+    err = np.abs(model.volume_lattice_forward(u3, Q)["pred_volume"][0].cpu().numpy() - g["wnf_volume"]).max()
+    if err > TOL:
+        pytest.xfail(f"bf16x2 preview arithmetic: WNF error {err:.2e} > {TOL:.0e} (known; the mode is not a default anywhere)")
+
+
+@pytest.mark.filterwarnings("ignore:garmentnets_amd. conv_mode bf16x2:RuntimeWarning")
 @pytest.mark.parametrize("planes", [0, 4, 3, 2])
 def test_pipeline_conv_modes(golden_dir, planes):
     """every conv arithmetic (0 = fp32 MFMA, 4 = f16x2 default, 3 / 2 = bf16 planes): the whole pipeline against the reference
