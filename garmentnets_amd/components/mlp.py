@@ -5,10 +5,45 @@ API / checkpoint-schema twin of /root/reference/components/mlp.py:3-20: ``MLP(ch
 AFTER the ReLU and also on the last layer.  The torch layers only HOLD the parameters; ``forward`` folds the eval-mode
 BatchNorm into a per-channel (scale, shift) and runs ``gn_linear`` (fp32 MFMA, fused bias+ReLU+affine epilogue).
 """
+import threading
+
 import torch
 from torch import nn
 
 from .. import ops
+
+
+class ParamCache:
+    """kernel-side packs derived from a module's parameters, shared by the host threads that run the module: `generation` names the
+    parameter state (device, tensor versions) -- a new one drops every older entry -- and `key` the variant (arithmetic, split point ...).
+    One lock per cache; entries are immutable once built; a reader that already holds an entry keeps it alive whatever happens to the table."""
+
+    def __init__(self):
+        self._lock, self._generation, self._items = threading.RLock(), None, {}
+
+    def get(self, generation, key, build):
+        with self._lock:
+            if generation != self._generation:
+                self._generation, self._items = generation, {}
+            v = self._items.get(key)
+            if v is None:
+                with torch.no_grad():
+                    v = self._items[key] = build()
+            return v
+
+    def __deepcopy__(self, memo):          # a copied / unpickled module starts with an empty cache
+        return ParamCache()
+
+    def __reduce__(self):
+        return (ParamCache, ())
+
+
+def param_cache(module, name):
+    """the module's ParamCache `name` (created on first use; not a parameter, not in the state dict)"""
+    c = module.__dict__.get(name)
+    if c is None:
+        c = module.__dict__.setdefault(name, ParamCache())
+    return c
 
 
 class PackedModule(nn.Module):

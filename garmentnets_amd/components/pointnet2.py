@@ -10,6 +10,7 @@ host-side sizes, so that no device synchronisation is needed on the hot path).
 """
 import os
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -36,6 +37,7 @@ class _DeviceTableCache:
             return t
 
 
+_DEBUG = threading.local()                # per host thread: SAModule -> its last graph (SAModule.last_graph)
 _PTR_CACHE = _DeviceTableCache()          # (sizes, device) -> CSR ptr
 _SELF_SRC_CACHE = _DeviceTableCache()     # (point sizes, centre sizes, device) -> per-example self-loop sources
 
@@ -133,8 +135,13 @@ class SAModule(torch.nn.Module):
             edges, slot_src, S = ops.sa_gather(x, pos, idx, nbr, self_loops=self.conv.add_self_loops, self_src=self_src)
             h = self.conv.local_nn(edges)
             out = ops.segment_max(h, slot_src, cseg.total, S)
-        self.last_graph = (idx, nbr)
+        _DEBUG.__dict__.setdefault("graphs", weakref.WeakKeyDictionary())[self] = (idx, nbr)
         return out, pos[idx.long()], cseg
+
+    @property
+    def last_graph(self):
+        """(fps indices, ball-query table) of THIS THREAD's last forward through this module -- a debugging / test aid, not read on the call path"""
+        return _DEBUG.__dict__.get("graphs", {}).get(self)
 
     def _fused_pack(self):
         """SaFusedPack of local_nn when it is one of the edge MLPs gn_sa_fused is instantiated for, else None (cached per parameter version)"""

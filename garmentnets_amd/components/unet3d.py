@@ -15,7 +15,7 @@ from torch import nn
 
 from .. import arith as AR
 from .. import ops
-from .mlp import PackedModule, pack_wb
+from .mlp import PackedModule, pack_wb, param_cache
 
 
 def number_of_features_per_level(init_channel_number, num_levels):
@@ -68,11 +68,8 @@ class SingleConv(PackedModule, nn.Sequential):
             # fp16 planes: the sample's activations are range-normalised by a power of two (exact, undone in the epilogue)
             a, d, act_inv = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta, with_act_scale=True) \
                 if mode == ops.SPLIT_F16X2 else ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta) + (None,)
-            cache = self.__dict__.setdefault("_split_packs", {})
-            key = (mode, self.conv.weight.device, self.conv.weight._version)
-            if key not in cache:
-                cache.clear()
-                cache[key] = ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device)
+            cache, gen = param_cache(self, "_split_packs"), (self.conv.weight.device, self.conv.weight._version)
+            wpack = cache.get(gen, mode, lambda: ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device))
             cout, sp = self.conv.out_channels, {}
             if (sparse is not None and arith.sparse_first_conv and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
                     and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]
@@ -82,7 +79,7 @@ class SingleConv(PackedModule, nn.Sequential):
                 if small_in is None:
                     small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
                 ncls = (2 * reach + 1) ** 3
-                small_out = ops.conv3d_gcr_split(small_in, None, a, d, cache[key], cout, relu=True, act_inv=act_inv)      # (a plain dense launch)
+                small_out = ops.conv3d_gcr_split(small_in, None, a, d, wpack, cout, relu=True, act_inv=act_inv)      # (a plain dense launch)
                 # class -> voxel of the 5^3 volume: reach 1 = voxels 0 / 2 / 4 per axis, reach 2 = all five (strided views: nothing is
                 # copied from the host, so the path can be captured into a HIP graph)
                 step = 2 if reach == 1 else 1
@@ -93,27 +90,24 @@ class SingleConv(PackedModule, nn.Sequential):
                 # polyphase form: the nearest-upsampled channels as a 2x2x2-tap convolution per output parity class on the COARSE volume
                 # (8/27 of their MACs, the coarse halo staged once for all classes: csrc/upconv.hip), added in the fine launch's epilogue
                 c0 = src0.shape[-1]
-                pkey = ("poly",) + key + (c0,)
-                if pkey not in cache:
+                def build_poly():
                     w0, wm, _ = ops.polyphase_weights(self.conv.weight, c0)
                     dev = self.conv.weight.device
-                    cache[pkey] = (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_upconv_weight(wm, cout, mode).to(dev))
-                pk0, pkm = cache[pkey]
+                    return (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_upconv_weight(wm, cout, mode).to(dev))
+                pk0, pkm = cache.get(gen, ("poly", mode, c0), build_poly)
                 part = ops.upconv_partial(src1, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, cout, act_inv=act_inv)
                 if rest0 is not None and arith.affine_in_weights and mode == ops.SPLIT_F16X2 and c0 % 16 == 0 and cout % 32 == 0:
                     # (a, d carry the sample's power-of-two activation scale: exact to undo)
                     a0 = (a[:, :c0] * act_inv[:, None]).contiguous()
                     d0 = (d[:, :c0] * act_inv[:, None]).contiguous()
-                    wkey = ("w0",) + key + (c0,)
-                    if wkey not in cache:
-                        cache[wkey] = self.conv.weight.detach()[:, :c0].contiguous()
-                    prep = ops.conv_affine_pack(cache[wkey], a0, d0, st0, rest0)
+                    w0c = cache.get(gen, ("w0", c0), lambda: self.conv.weight.detach()[:, :c0].contiguous())
+                    prep = ops.conv_affine_pack(w0c, a0, d0, st0, rest0)
                     r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, partial=part)
                     return r if with_stats else (r, None)
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)
                 return r if with_stats else (r, None)
-            r = ops.conv3d_gcr_split(src0, src1, a, d, cache[key], cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
+            r = ops.conv3d_gcr_split(src0, src1, a, d, wpack, cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
             return r if with_stats else (r, None)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
         if with_stats:

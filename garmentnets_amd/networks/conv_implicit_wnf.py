@@ -7,6 +7,8 @@ Keeps the reference's class names, constructor kwargs, sub-module names (= check
 (:340-452) is out of scope.  Feature volumes are stored channel-last; the (B,C,D,H,W) tensors handed out are views.
 """
 import os
+import threading
+import weakref
 
 import torch
 from torch import nn
@@ -14,8 +16,9 @@ from torch import nn
 from .. import arith as AR
 from .. import ops
 from ..batch import Batch
-from ..components.mlp import MLP, PackedModule, fold_batchnorm
+from ..components.mlp import MLP, PackedModule, fold_batchnorm, param_cache
 from ..components.unet3d import Abstract3DUNet, DoubleConv, to_channel_last
+from ..components.pointnet2 import Segments
 from .pointnet2_nocs import PointNet2NOCS
 
 
@@ -44,25 +47,26 @@ class VolumeFeatureAggregator(nn.Module):
         if C is None:
             return
         dev = _normalise_device(device)
-        pre = self.__dict__.get("_prezero")
+        state = _THREAD_STATE.of(self)
+        pre = state.get("prezero")
         if pre is not None and pre[0] == B and pre[1].device == dev:
             return                                   # an earlier prefetch of this shape was never consumed: still zero
         if B * int(torch.tensor(self.grid_shape).prod()) * C * 4 < (64 << 20):
             return                                   # small volumes: the in-stream memset costs microseconds
         main = torch.cuda.current_stream(dev)
-        side = self.__dict__.get("_side")
+        side = state.get("side")
         if side is None or side.device != dev:
-            side = self.__dict__["_side"] = torch.cuda.Stream(device=dev)
+            side = state["side"] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)                       # the blocks the allocator hands out were last used on the main stream
         with torch.cuda.stream(side):
             vol, cnt = ops.zeroed_volume(B, self.grid_shape, C, dev)
             ev = torch.cuda.Event()
             ev.record(side)
-        self.__dict__["_prezero"] = (B, vol, cnt, ev)
+        state["prezero"] = (B, vol, cnt, ev)
 
     def drop_prefetch(self):
         """release an unconsumed prefetch_zero buffer (17 GB at batch 16, 128^3)"""
-        pre = self.__dict__.pop("_prezero", None)
+        pre = _THREAD_STATE.of(self).pop("prezero", None)
         if pre is not None:
             pre[1].record_stream(torch.cuda.current_stream(pre[1].device))     # filled on the side stream, freed from this one
 
@@ -74,7 +78,7 @@ class VolumeFeatureAggregator(nn.Module):
                                         self.include_point_feature, self.include_confidence_feature)
         if self.local_nn is not None:
             feats = self.local_nn(feats)
-        pre = self.__dict__.pop("_prezero", None)
+        pre = _THREAD_STATE.of(self).pop("prezero", None)
         prezeroed = None
         if pre is not None and torch.cuda.is_current_stream_capturing():
             pre = None                                # a captured graph must own its memset: never bake "already zero" into it
@@ -86,6 +90,25 @@ class VolumeFeatureAggregator(nn.Module):
         out._gn_stats = stats      # GroupNorm statistics of the (mostly empty) volume, from its occupied cells only
         out._gn_flat = flat        # the occupied cells: the first UNet convolution only visits the tiles that can see one
         return out
+
+
+class _PerThreadState:
+    """per (host thread, module instance) scratch state: the prefetched zero volume and its side stream belong to the thread that asked
+    for them -- two threads sharing one model never consume or drop each other's buffer (no shared mutable state on the
+    call path).  Entries die with the module (weak keys) or the thread."""
+
+    def __init__(self):
+        self._tls = threading.local()
+
+    def of(self, module):
+        table = self._tls.__dict__.setdefault("table", weakref.WeakKeyDictionary())
+        st = table.get(module)
+        if st is None:
+            st = table[module] = {}
+        return st
+
+
+_THREAD_STATE = _PerThreadState()
 
 
 def _normalise_device(device):
@@ -152,26 +175,24 @@ class ImplicitWNFDecoder(PackedModule):
                 and ch[2] % 256 == 0 and ch[3] <= 4 and final_conv.kernel_size == (1, 1, 1)):
             return None
         key = (id(final_conv), final_conv.weight._version, final_conv.bias._version, final_conv.weight.device) + tuple(p._version for p in self.parameters())
-        cache = self.__dict__.setdefault("_folded", {})
-        if key not in cache:
-            cache.clear()
-            with torch.no_grad():
-                wf = final_conv.weight.detach().double().reshape(final_conv.out_channels, final_conv.in_channels)
-                bf = final_conv.bias.detach().double()
-                layers, raw = [], []
-                for i, block in enumerate(self.mlp):
-                    w = block[0].weight.detach().double()
-                    b = block[0].bias.detach().double()
-                    if i == 0:
-                        b = b + w @ bf
-                        w = w @ wf
-                    w, b = w.float(), b.float().contiguous()
-                    sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
-                    layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
-                    raw.append((w, b, sc, sh))
-                split = ops.pack_decode_split(raw).to(w.device) if (final_conv.in_channels, ch[1], ch[2]) == (32, 256, 256) else None
-                cache[key] = tuple(layers) + (split,)
-        return cache[key]
+
+        def build():
+            wf = final_conv.weight.detach().double().reshape(final_conv.out_channels, final_conv.in_channels)
+            bf = final_conv.bias.detach().double()
+            layers, raw = [], []
+            for i, block in enumerate(self.mlp):
+                w = block[0].weight.detach().double()
+                b = block[0].bias.detach().double()
+                if i == 0:
+                    b = b + w @ bf
+                    w = w @ wf
+                w, b = w.float(), b.float().contiguous()
+                sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
+                layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
+                raw.append((w, b, sc, sh))
+            split = ops.pack_decode_split(raw).to(w.device) if (final_conv.in_channels, ch[1], ch[2]) == (32, 256, 256) else None
+            return tuple(layers) + (split,)
+        return param_cache(self, "_folded").get(key, "folded", build)
 
     def _decode_rows(self, vol_b, out, query=None, Q=0, layers=None, xscale=None, arith=None):
         """vol_b [D][H][W][C]: the decoder's own input volume, or (with the folded `layers`) the UNet's pre-final volume;
@@ -400,10 +421,11 @@ class ConvImplicitWNFPipeline(nn.Module):
         sizes = data._sizes if hasattr(data, "_sizes") else None
         if prefetch_volume and sizes is not None and data.pos.is_cuda:   # (no host sizes: the batch size would cost a device synchronisation here)
             self.volume_agg.prefetch_zero(len(sizes), data.pos.device)
-        result = self.pointnet2_nocs(data)
+        seg = Segments.of(data.batch, sizes if sizes is not None else getattr(data, "sizes", None))     # the batch's sizes travel with THIS call
+        result = self.pointnet2_nocs(data, seg=seg)
         bins = self.pointnet2_nocs.nocs_bins
         _, confidence, pred_nocs = ops.nocs_head(result["per_point_logits"], bins)
-        result["nocs_data"] = Batch(sizes=self.pointnet2_nocs.last_sizes, x=result["per_point_features"], pos=pred_nocs, batch=result["per_point_batch_idx"],
+        result["nocs_data"] = Batch(sizes=seg.sizes, x=result["per_point_features"], pos=pred_nocs, batch=result["per_point_batch_idx"],
                                     sim_points=data.pos, pred_confidence=confidence)
         return result
 

@@ -49,11 +49,13 @@ class PointNet2NOCS(nn.Module):
         self.sa1_module.conv.self_loop_scope = self.sa2_module.conv.self_loop_scope = scope
         return self
 
-    def forward(self, data):
-        """data: .x (N,3) rgb, .pos (N,3), .batch (N,) sorted int64 [, .sizes host list] -- eval mode (dropout = identity)."""
-        sizes = data._sizes if hasattr(data, "_sizes") else getattr(data, "sizes", None)
-        seg = Segments.of(data.batch, sizes)
-        self.last_sizes = seg.sizes
+    def forward(self, data, seg=None):
+        """data: .x (N,3) rgb, .pos (N,3), .batch (N,) sorted int64 [, .sizes host list] -- eval mode (dropout = identity).
+        seg: the batch's Segments when the caller already has them (ConvImplicitWNFPipeline.pointnet2_forward: sizes travel with the call,
+        nothing about a batch is parked on the shared module)"""
+        if seg is None:
+            sizes = data._sizes if hasattr(data, "_sizes") else getattr(data, "sizes", None)
+            seg = Segments.of(data.batch, sizes)
         x = data.x.float().contiguous()
         pos = data.pos.float().contiguous()
         sa0 = (x, pos, seg)
