@@ -577,7 +577,7 @@ def test_predict_main_subset_and_batched_cli(tmp_path):
     PR.main(common + ["--zarr_out", str(tmp_path / "p_test.zarr"), "--subset", "test"])
     ids = [f"{i:05d}_Dress" for i in range(10)]
     want = instance_split(ids, (8, 1, 1), 0)["test"]
-    assert len(want) == 1 and sorted(os.listdir(tmp_path / "p_test.zarr" / "samples")) == [keys[int(i)] for i in want]
+    assert len(want) == 1 and sorted(d for d in os.listdir(tmp_path / "p_test.zarr" / "samples") if not d.startswith(".")) == [keys[int(i)] for i in want]
     ds = GarmentInputDataset(din, num_pc_sample=1500, num_views=3, static_epoch_seed=True, random_rot_range=(-180, 180))
     item = ds[int(want[0])]
     got_pts = _zarr_v2_read(str(tmp_path / "p_test.zarr"), os.path.join("samples", keys[int(want[0])], "point_cloud", "input_points"))
