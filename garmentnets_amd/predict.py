@@ -278,17 +278,18 @@ class PredictJob:
 
 
 def predict_stream(model, batches, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
-                   use_hole_prediction=False, arith=None):
+                   use_hole_prediction=False, arith=None, host=False):
     """generator over an iterable of batches -> the predict_batch result of each, in order, with one batch in flight behind the one
-    being finished (PredictJob)"""
+    being finished (PredictJob).  host=True: every batch comes back as [to_host(r) for r in results] -- the numpy mesh dicts predict.py
+    writes -- copied to pinned host memory on the tail stream while the next batch's dense path runs"""
     prev = None
     for batch in batches:
         job = PredictJob(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, arith)
         if prev is not None:
-            yield prev.finish()
+            yield prev.finish(host=host)
         prev = job
     if prev is not None:
-        yield prev.finish()
+        yield prev.finish(host=host)
 
 
 def _d2h(tensors):

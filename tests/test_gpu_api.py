@@ -246,6 +246,15 @@ def test_predict_stream_equals_predict_batch():
                 assert torch.equal(torch.nan_to_num(a.double(), nan=-7.0), torch.nan_to_num(b.double(), nan=-7.0)), k
             n_real += int(not torch.isnan(r["verts"]).any())
     assert n_real >= 3
+    # the host path (SURVEY.md 8d's metric includes the D2H copy of every mesh): finish(host=True) copies on the tail stream -- same bytes
+    got_host = list(predict_stream(model, batches, volume_size=32, iso_surface_level=level, use_hole_prediction=True, host=True))
+    for rb, hb in zip(ref, got_host):
+        for r, hres in zip(rb, hb):
+            want = to_host(r)
+            assert set(want) == set(hres)
+            for k in want:
+                assert isinstance(hres[k], np.ndarray) and want[k].dtype == hres[k].dtype
+                assert np.array_equal(want[k], hres[k], equal_nan=want[k].dtype.kind == "f"), k
     # twice over the same batches (the tail stream reused), interleaved with a plain predict_batch on the main stream
     j0 = PredictJob(model, batches[1], 32, level)              # (every job owns its buffers)
     j1 = PredictJob(model, batches[2], 32, level)
