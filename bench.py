@@ -46,7 +46,11 @@ INPUT (--input planted, the default): the seeded global batch of synthetic.synth
 synthetic checkpoint with synthetic.plant_nocs_path -- the NOCS head decodes the clouds' colour channels (:= the garment's normalised,
 64-bin quantised positions), so the predicted NOCS coordinates spread over the garment's own shape: ~4900 occupied cells of the 128^3
 grid per garment, the occupancy a trained PointNet++ produces, a well-conditioned input on which the north-star tolerance (1e-4 on the
-WNF against the oracle) is enforced by tests/test_gpu_fullsize.py::test_bench_batch_against_oracle on THIS batch.  --input collapsed:
+WNF against the oracle) is enforced by tests/test_gpu_fullsize.py::test_bench_batch_against_oracle on THIS batch.  The checkpoint also
+carries synthetic.plant_wnf_path: a carrier path through the UNet and the WNF decoder (multi-scale blur of the occupancy) that makes the
+0.5 level set a thin shell around the garment -- a real garment's mesh size (tens of thousands of vertices) instead of the ~500 k-vertex
+sponge random decoder weights give, so the iso-surface tail, the surface decoder and the host copies are timed on a garment-like amount of
+work.  --input noisy_wnf: round 3's input (planted NOCS path only; the random-weight WNF as the tail's stress case).  --input collapsed:
 rounds 1-2's input (uniform colours, un-planted random weights: every cloud collapses into ~5 cells; GroupNorm over a >99.99 % empty
 volume amplifies rounding ~100x -- a conditioning study, not a headline).
 """
@@ -81,8 +85,10 @@ def parse():
     ap.add_argument("--grid", type=int, default=128, help="feature-volume edge G (north_star: 128; reference ckpt default: 32)")
     ap.add_argument("--reduce", default="mean", choices=["mean", "max"])
     ap.add_argument("--volume-size", type=int, default=128, help="WNF query volume edge Q")
-    ap.add_argument("--input", default="planted", choices=["planted", "collapsed"],
-                    help="planted (default): position-coloured clouds + the planted NOCS path (realistic occupancy, well conditioned); collapsed: "
+    ap.add_argument("--input", default="planted", choices=["planted", "noisy_wnf", "collapsed"],
+                    help="planted (default): position-coloured clouds + the planted NOCS path (realistic occupancy, well conditioned) + the planted WNF "
+                         "carrier (garment-like shell, a real garment's mesh size); noisy_wnf: round 3's input -- the planted NOCS path only, the WNF is "
+                         "random-weight noise with ~10x a real garment's vertices (the stress case for the iso-surface tail); collapsed: "
                          "rounds 1-2's degenerate input (conditioning study)")
     ap.add_argument("--conv-mode", default="f16x2", choices=["f16x2", "fp32", "bf16x3", "bf16x2"],
                     help="arithmetic of the 3x3x3 convs of the HEADLINE pass: f16x2 (default; fp32 operands split into two fp16 planes, fp32 "
@@ -403,9 +409,9 @@ def bench_inputs(batch, points, grid, reduce, input_kind, rank=0, world=1):
     """the benchmark's model inputs: (hparams, state dict, this rank's shard of the seeded global batch on the host, (lo, hi)).
     tests/test_gpu_fullsize.py::test_bench_batch_against_oracle calls this to check THE batch the number is quoted on."""
     from garmentnets_amd import parallel, synthetic as S
-    planted = input_kind == "planted"
+    planted = input_kind in ("planted", "noisy_wnf")
     hp = S.default_hparams(grid=grid, reduce_method=reduce)
-    sd = S.synthetic_state_dict(hp, 0, planted_nocs=planted)
+    sd = S.synthetic_state_dict(hp, 0, planted_nocs=planted, planted_wnf=input_kind == "planted")
     shard, span = parallel.shard_batch(batch * world, points, CLOUD_SEED, rank, world, colour="position" if planted else "uniform")
     return hp, sd, shard, span
 
@@ -486,7 +492,7 @@ def validate(model, args, dev, auto_level):
     saved = (pn.sa1_module.conv.add_self_loops, pn.sa2_module.conv.add_self_loops)
     pn.sa1_module.conv.add_self_loops = pn.sa2_module.conv.add_self_loops = False
     try:
-        x, pos, _ = S.synthetic_cloud(1, n, seed=4242, colour="position" if args.input == "planted" else "uniform")
+        x, pos, _ = S.synthetic_cloud(1, n, seed=4242, colour="position" if args.input != "collapsed" else "uniform")
         data = Batch(sizes=[n] * B, x=x.repeat(B, 1), pos=pos.repeat(B, 1), batch=torch.arange(B).repeat_interleave(n)).to(dev)
         if args.workload == "pointnet2":
             with torch.no_grad():
@@ -765,9 +771,11 @@ def main():
         dtype = "f32" if not split and args.decode_mode == "fp32" else (
             f"f32 ({args.conv_mode} operand split on the 16-bit matrix cores for the 3x3x3 convs" + (" and the decoder MLPs" if args.decode_mode == "f16x2" else "") +
             ", fp32 accumulation; everything else fp32/fp64)" if split else "f32 (f16x2 operand split for the decoder MLPs only)")
-        if args.input == "planted":
+        if args.input != "collapsed":
             input_note = ("position-coloured synthetic dress clouds + seeded synthetic checkpoint with the planted NOCS path (synthetic.plant_nocs_path): "
-                          "predicted NOCS spread over the garment's shape, realistic occupancy")
+                          "predicted NOCS spread over the garment's shape, realistic occupancy" + (
+                              "; planted WNF carrier (synthetic.plant_wnf_path): the 0.5 level set is a thin shell around the garment, a real garment's "
+                              "mesh size" if args.input == "planted" else "; WNF = random-weight noise (~10x a real garment's vertices: the tail's stress case)"))
         else:
             input_note = "uniform-colour synthetic dress clouds + un-planted seeded random weights: every cloud collapses into a handful of cells (conditioning study)"
         if args.workload == "pointnet2":
@@ -790,7 +798,11 @@ def main():
                        "sharding": f"garments [r*{args.batch}, (r+1)*{args.batch}) of one seeded global batch per rank (parallel.shard_range)",
                        "points": args.points, "grid": args.grid, "reduce": args.reduce,
                        "volume_size": args.volume_size, "iso_level": "mid(min,max)" if auto_level[0] else 0.5,
-                       "weights": "seeded synthetic (reference architecture)" + (" + planted NOCS path" if args.input == "planted" else ""),
+                       "weights": "seeded synthetic (reference architecture)" + (" + planted NOCS path" if args.input != "collapsed" else "") + (
+                           " + planted WNF carrier path" if args.input == "planted" else ""),
+                       "wnf_input": {"planted": "garment-like: smooth shell around the garment (synthetic.plant_wnf_path)", "noisy_wnf": "random-weight noise (stress case)",
+                                     "collapsed": "random-weight noise"}[args.input],
+                       "mesh_verts_per_garment": (verts_total / (hi - lo)) if verts_total is not None else None,
                        "encoder_convs": "dense: every tile through the matrix cores (occupancy-aware launch OFF for the headline)" + (
                            "; GroupNorm affine of the two convolutions behind the scattered volume folded into per-sample weights + a bias table, operand exactly zero in "
                            "empty cells (Arith.affine_in_weights; the literal form is timed as literal_affine)" if headline.affine_in_weights and args.conv_mode == "f16x2" else ""), "mesh_verts_per_step": verts_total,

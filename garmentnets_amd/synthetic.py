@@ -118,10 +118,15 @@ def synthetic_tensor(key, shape, seed=0):
     raise KeyError(key)
 
 
-def synthetic_state_dict(hp, seed=0, planted_nocs=False):
-    """planted_nocs: see plant_nocs_path (bench.py's default weights)"""
+def synthetic_state_dict(hp, seed=0, planted_nocs=False, planted_wnf=False):
+    """planted_nocs: see plant_nocs_path; planted_wnf: see plant_wnf_path (True = its defaults, or a dict of its keyword arguments) --
+    bench.py's default weights carry both"""
     sd = {k: synthetic_tensor(k, shp, seed) for k, shp in state_dict_spec(hp)}
-    return plant_nocs_path(sd, hp) if planted_nocs else sd
+    if planted_nocs:
+        sd = plant_nocs_path(sd, hp)
+    if planted_wnf:
+        sd = plant_wnf_path(sd, hp, **(planted_wnf if isinstance(planted_wnf, dict) else {}))
+    return sd
 
 
 NOCS_PLANT_GAP = 8.0      # logit margin between the planted arg-max bin and its neighbours
@@ -172,6 +177,140 @@ def plant_nocs_path(sd, hp, prefix="pointnet2_nocs"):
         b[a::3] = b[a::3] - (s * k * k).float()
     sd[f"{prefix}.lin3.weight"], sd[f"{prefix}.lin3.bias"] = w, b
     return sd
+
+
+WNF_PLANT = dict(gain=1.0, offset=0.1, cut=0.35, ramp=8.0, noise=0.01)      # tuned on the 128^3 / mean benchmark configuration
+
+
+def plant_wnf_path(sd, hp, gain=None, offset=None, cut=None, ramp=None, noise=None):
+    """Seeded random weights make the winding-number field random-weight noise: its 0.5 level set is a sponge of ~500 k vertices per
+    garment, ten times a real garment's 40-60 k, so everything behind the lattice decoder (marching cubes, the surface decoder, the D2H
+    copy of the mesh) is timed on the wrong amount of work.  This plants, inside the reference's schema and next to the random weights, a
+    CARRIER path whose output is a smooth field that is high near the garment and zero away from it -- the level set becomes a thin shell
+    hugging (part of) the garment's surface:
+
+      volume_agg.local_nn (last layer)   channels of GroupNorm group 0 of the UNet's input: ReLU(ramp (x_0 - cut)) clamped to 1 by the
+                                         following layer's normalisation -- a per-point amplitude that switches the carrier on over the part
+                                         of the garment with planted colour / position coordinate x_0 > cut (point feature 0 = the planted
+                                         NOCS path's x_0; without plant_nocs_path it is a random feature and the shell is simply irregular)
+      every UNet convolution             carrier rows: a 3x3x3 box average over the carrier channels of its input (GroupNorm group 0; the
+                                         decoders' first convolutions also read the LAST group, which lies in the upsampled source), zero
+                                         on every other input channel; GroupNorm affine of carrier channels = identity.  Level by level this
+                                         is a multi-scale blur of the occupancy, renormalised by each GroupNorm; the ReLUs keep it >= 0 and
+                                         exactly 0 where the volume is at rest
+      final 1x1x1 convolution            output channel 0 = mean of the last layer's carrier channels
+      volume_decoder.mlp                 hidden unit 0 of both hidden layers passes feature 0 through; the output layer is
+                                         gain * carrier + offset + noise * (the random hidden units' contribution, unit variance)
+                                         and its BatchNorm is the identity, so WNF = ReLU(that)
+
+    The other output rows of every layer keep their random weights (and read the carrier channels like any other input): the kernels do
+    the same work on the same shapes.  The surface (warp-field) decoder is left random."""
+    cfg = dict(WNF_PLANT)
+    cfg.update({k: v for k, v in dict(gain=gain, offset=offset, cut=cut, ramp=ramp, noise=noise).items() if v is not None})
+    sd = dict(sd)
+    u = hp["unet3d_params"]
+    groups = u.get("num_groups", 8)
+    plan, f_maps = unet_plan(u["in_channels"], u["f_maps"], u.get("num_levels", 4))
+    up = "unet_3d.abstract_3d_unet"
+    nenc = len(f_maps)
+
+    def group(cin, g):
+        gs = cin // groups
+        return list(range(g * gs, (g + 1) * gs))
+
+    def plant_conv(prefix, cin, carriers_in, carriers_out):
+        w = sd[prefix + ".conv.weight"].clone()
+        w[carriers_out] = 0.0
+        row = torch.zeros(cin, 3, 3, 3)
+        row[carriers_in] = 1.0 / (27.0 * len(carriers_in))
+        w[carriers_out] = row
+        sd[prefix + ".conv.weight"] = w
+        gw, gb = sd[prefix + ".groupnorm.weight"].clone(), sd[prefix + ".groupnorm.bias"].clone()
+        gw[carriers_in], gb[carriers_in] = 1.0, 0.0
+        sd[prefix + ".groupnorm.weight"], sd[prefix + ".groupnorm.bias"] = gw, gb
+
+    # what the consumers of every module's OUTPUT read as carriers
+    def out_carriers(k):
+        mod, c1, c2 = plan[k]
+        cout = c2[1]
+        if k < nenc - 1:                                  # encoder: next encoder's first conv + its decoder's skip group 0
+            nxt = group(plan[k + 1][1][0], 0)
+            skip_cin = plan[2 * nenc - 2 - k][1][0]       # decoder that takes this encoder's output as skip
+            return sorted(set(nxt) | set(group(skip_cin, 0)))
+        if k < len(plan) - 1:                             # deepest encoder / a decoder: the next decoder's LAST group, in the upsampled part
+            cat_cin = plan[k + 1][1][0]
+            skip_c = cat_cin - cout
+            return [c - skip_c for c in group(cat_cin, groups - 1)]
+        return group(cout, 0)                             # last decoder -> final conv
+
+    for k, (mod, c1, c2) in enumerate(plan):
+        cin = c1[0]
+        cin_carriers = group(cin, 0)
+        if k >= nenc:                                     # decoder: concatenated (skip, upsampled) input
+            cin_carriers = cin_carriers + group(cin, groups - 1)
+        mid = group(c1[1], 0)
+        plant_conv(f"{up}.{mod}.basic_module.SingleConv1", cin, cin_carriers, mid)
+        plant_conv(f"{up}.{mod}.basic_module.SingleConv2", c2[0], mid, out_carriers(k))
+    # final 1x1x1: output channel 0 <- mean of the last decoder's carriers
+    fw, fb = sd[up + ".final_conv.weight"].clone(), sd[up + ".final_conv.bias"].clone()
+    last = group(f_maps[0], 0)
+    fw[0] = 0.0
+    fw[0, last] = 1.0 / len(last)
+    fb[0] = 0.0
+    sd[up + ".final_conv.weight"], sd[up + ".final_conv.bias"] = fw, fb
+    # the UNet's input carriers: volume_agg's last layer, amplitude ReLU(ramp (x_0 - cut)) of point feature 0
+    va = hp["volume_agg_params"]
+    nl = len(va["nn_channels"]) - 2
+    p = f"volume_agg.local_nn.{nl}"
+    in_carriers = group(u["in_channels"], 0)
+    if nl == 0:
+        w, b = sd[p + ".0.weight"].clone(), sd[p + ".0.bias"].clone()
+        w[in_carriers] = 0.0
+        w[in_carriers, 0] = cfg["ramp"]
+        b[in_carriers] = -cfg["ramp"] * cfg["cut"]
+    else:                                                 # hidden layer first: pass point feature 0 through hidden unit 0 (>= 0: a planted colour in [0.1, 0.9])
+        p0 = f"volume_agg.local_nn.{nl - 1}"
+        w0, b0 = sd[p0 + ".0.weight"].clone(), sd[p0 + ".0.bias"].clone()
+        w0[0] = 0.0
+        w0[0, 0] = 1.0
+        b0[0] = 0.0
+        sd[p0 + ".0.weight"], sd[p0 + ".0.bias"] = w0, b0
+        _identity_bn(sd, p0, [0], va.get("batch_norm", True))
+        w, b = sd[p + ".0.weight"].clone(), sd[p + ".0.bias"].clone()
+        w[in_carriers] = 0.0
+        w[in_carriers, 0] = cfg["ramp"]
+        b[in_carriers] = -cfg["ramp"] * cfg["cut"]
+    sd[p + ".0.weight"], sd[p + ".0.bias"] = w, b
+    _identity_bn(sd, p, in_carriers, va.get("batch_norm", True))
+    # the WNF decoder: feature 0 through hidden unit 0 of both hidden layers, then gain * carrier + offset (+ a little of everything else)
+    dch = list(hp["volume_decoder_params"]["nn_channels"])
+    dbn = hp["volume_decoder_params"].get("batch_norm", True)
+    for i in range(len(dch) - 2):
+        q = f"volume_decoder.mlp.{i}"
+        w, b = sd[q + ".0.weight"].clone(), sd[q + ".0.bias"].clone()
+        w[0] = 0.0
+        w[0, 0] = 1.0
+        b[0] = 0.0
+        sd[q + ".0.weight"], sd[q + ".0.bias"] = w, b
+        _identity_bn(sd, q, [0], dbn)
+    q = f"volume_decoder.mlp.{len(dch) - 2}"
+    w, b = sd[q + ".0.weight"].clone(), sd[q + ".0.bias"].clone()
+    rest = w[:, 1:]
+    w[:, 1:] = rest / rest.norm(dim=1, keepdim=True).clamp_min(1e-12) * cfg["noise"]     # unit-variance hidden units -> std `noise`
+    w[:, 0] = cfg["gain"]
+    b[:] = cfg["offset"]
+    sd[q + ".0.weight"], sd[q + ".0.bias"] = w, b
+    _identity_bn(sd, q, list(range(dch[-1])), dbn)
+    return sd
+
+
+def _identity_bn(sd, layer_prefix, channels, batch_norm=True):
+    if not batch_norm:
+        return
+    for key, val in ((".2.weight", 1.0), (".2.bias", 0.0), (".2.running_mean", 0.0), (".2.running_var", 1.0)):
+        t = sd[layer_prefix + key].clone()
+        t[channels] = val
+        sd[layer_prefix + key] = t
 
 
 def synthetic_cloud(num_garments, n_points=6000, seed=0, first=0, colour="uniform"):
