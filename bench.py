@@ -208,6 +208,24 @@ class KernelTimer:
         return groups
 
 
+GGM_FP64_INSTR_PER_VOXEL = 120.0     # 9 five-tap symmetric correlations (7 fp64 instructions + 5 fp32->fp64 conversions each) + squares, sums, sqrt
+GGM_LDS_BYTES_PER_VOXEL = 59 * 4.0   # sliding-window reads + inter-pass writes of the fused kernel (csrc/iso.hip ggm_fused_kernel)
+
+
+def measured_roofs():
+    """fp64 vector rate and LDS read rate measured on THIS box by tools/dev/roof_burn (built by __graft_entry__.build()): the ceilings of
+    the members whose arithmetic is fp64 by contract (scipy / scikit-image bit-exactness).  -> dict or None"""
+    import subprocess
+    exe = os.path.join(REPO, "tools", "dev", "_build", "roof_burn")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 class HbmMembers:
     """HIP-event brackets around the HBM-bound members of the path (zero-fill, scatter, max-pool, sampler, GGM, min/max,
     MC33) during ONE untimed step; bytes = ALGORITHMIC bytes of the call (each input / output once), fraction of the 8 TB/s HBM3E peak.
@@ -295,6 +313,28 @@ class HbmMembers:
                 gbs = b_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 sh[k] = {"ms": ms, "algorithmic_bytes": b_, "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
             out["iso_on_shell_volume"] = sh
+        roofs = measured_roofs()
+        if roofs is not None:
+            out["roofs"] = dict(roofs, public_spec={"fp64_vector_tflops": 78.6, "lds_TBs": "256 CUs x 128 B/clk x 2.4 GHz = 78.6"},
+                                note="measured on this box right before this line was printed (tools/dev/roof_burn.hip)")
+            instr_rate = roofs["fp64_fma_tflops"] * 1e12 / 2.0          # fp64 vector instructions per second (an FMA counts 2 FLOP)
+
+            def ggm_roofs(entry, voxels):
+                sec = entry["ms"] * 1e-3
+                entry["fp64_instr_per_voxel"] = GGM_FP64_INSTR_PER_VOXEL
+                entry["frac_of_fp64_rate"] = GGM_FP64_INSTR_PER_VOXEL * voxels / sec / instr_rate
+                entry["lds_bytes_per_voxel"] = GGM_LDS_BYTES_PER_VOXEL
+                entry["frac_of_lds_rate"] = GGM_LDS_BYTES_PER_VOXEL * voxels / sec / (roofs["lds_read_TBs"] * 1e12)
+            if "ggm3d_batch" in out and wnf_all is not None:
+                ggm_roofs(out["ggm3d_batch"], float(wnf_all.numel()) * out["ggm3d_batch"]["calls"])
+            if "iso_on_shell_volume" in out and wnf_all is not None:
+                ggm_roofs(out["iso_on_shell_volume"]["ggm3d_batch"], float(wnf_all.numel()))
+            for grp in (out.get("mc33_stages"), out.get("iso_on_shell_volume")):
+                if grp and "mesh_vertices_per_batch" in grp and grp["mesh_vertices_per_batch"]:
+                    nv = float(grp["mesh_vertices_per_batch"])
+                    for k, v in grp.items():
+                        if isinstance(v, dict) and k.startswith("mc_") and "ms" in v:
+                            v["ns_per_vertex"] = v["ms"] * 1e6 / nv
         out["note"] = ("one untimed step; bytes = algorithmic (each input / output of the call once); scatter is atomics / latency-bound by nature "
                        "(6000 points per garment), zero-fill runs on a side stream beside farthest-point sampling; GGM is ONE fused launch whose 9 "
                        "fp64 5-tap correlations per voxel (scipy's arithmetic, bit for bit) make it fp64-ALU / LDS bound, not HBM bound; the MC33 "

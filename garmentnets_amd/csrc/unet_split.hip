@@ -1141,7 +1141,12 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     // 128-wide variant: two-plane modes, Cout % 128 == 0, at least two workgroups per CU's worth of work (its row loads address one sample of
     // the full-resolution source with 32-bit byte offsets)
     const bool wide128 = mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && fits32 && (int64_t)tiles * (Cout / 128) * B >= 512;
-    const bool wide = !wide128 && (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
+    // x-strip variant (below) also for the 64-wide layers with one full-resolution source: two 32-wide column blocks through the strip kernel
+    // (18 fragment reads per 36 MFMAs) beat the 64-wide form of conv3d_split_kernel (8 per 12) by 4-7 % on every such shape of the UNet, the
+    // halo staged twice notwithstanding (profiles/r04_ab_experiments.txt); bit-identical outputs
+    const int tiles8 = (int)gn_cdiv(D, 8) * p.tiles_y * p.tiles_x;
+    const bool strip = mode != GN_SPLIT_BF16X3 && !wide128 && C1 == 0 && (int64_t)tiles8 * (Cout / 32) * B >= 512;
+    const bool wide = !wide128 && !strip && (Cout % 64 == 0) && ((int64_t)tiles * (Cout / 64) * B >= 1024);
     // (MT = 2, the tall 8 x 8 x 8 tile, was measured on the 32-wide layers: 327-347 TFLOP/s vs 340 for MT = 1 -- its synchronous
     //  staging phase is 29 % of the kernel -- so it is not dispatched)
 #define SP_LAUNCH(P_, F16_)                                                                                                    \
@@ -1159,9 +1164,6 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
                                           "filled with the border-class constants alone: the partial would be dropped there)");
     GN_REQUIRE(!tile_active || ((kreach == 1 || kreach == 2) && mode != GN_SPLIT_BF16X3 && D > 2 * kreach && H > 2 * kreach && W > 2 * kreach),
                "gn_conv3d_gcr_split: the occupancy-aware launch needs a two-plane mode, kreach 1 or 2 and dims > 2 kreach");
-    // x-strip variant for the column blocks the 64- and 128-wide kernels do not take (two-plane modes, one full-resolution source)
-    const int tiles8 = (int)gn_cdiv(D, 8) * p.tiles_y * p.tiles_x;
-    const bool strip = mode != GN_SPLIT_BF16X3 && !wide128 && !wide && C1 == 0 && (int64_t)tiles8 * (Cout / 32) * B >= 512;
     if (tile_active) {
         // the active tiles as a compact list at the chosen kernel's tile granularity + the inactive tiles' constants (and their statistics)
         GN_REQUIRE(occ_ws && occ_ws_bytes >= gn_conv3d_occupancy_workspace_bytes(B, D, H, W) && ((uintptr_t)occ_ws & 3) == 0,
