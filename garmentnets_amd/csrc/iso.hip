@@ -369,6 +369,19 @@ struct McDims {
     int64_t s_cinfo, s_cnt, s_edge, s_bsum, s_verts, s_faces;
 };
 
+// sweep index -> (x, y, z) of a row-major (n1 x n2 inner) grid.  Grids of fewer than 2^32 elements (every lattice predict.py asks for) take two
+// 32-bit unsigned divisions; the 64-bit divide / modulo triple this replaces was ~300 instructions per cell -- the whole cost of the classify pass
+__device__ __forceinline__ void mc_unflatten(int64_t i, int n1, int n2, int64_t total, int &x, int &y, int &z) {
+    if (total < ((int64_t)1 << 32)) {                  // (uniform)
+        const unsigned u = (unsigned)i, q = u / (unsigned)n2, zz = q / (unsigned)n1;
+        x = (int)(u - q * (unsigned)n2);
+        y = (int)(q - zz * (unsigned)n1);
+        z = (int)zz;
+    } else {
+        x = (int)(i % n2); y = (int)((i / n2) % n1); z = (int)(i / ((int64_t)n1 * n2));
+    }
+}
+
 // corner values minus level, Lewiner numbering: v0=(0,0,0) v1=(x+1) v2=(x+1,y+1) v3=(y+1) v4..v7 at z+1
 __device__ __forceinline__ void mc_load_cell(const float *__restrict__ vol, const McDims &d, int x, int y, int z, double level,
                                              double v[8]) {
@@ -584,7 +597,8 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
         const int64_t ci = wg0 + k * 256 + threadIdx.x;
         index[k] = 0;
         if (ci < d.ncells) {
-            const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+            int x, y, z;
+            mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
             mc_load_cell(vol, d, x, y, z, level, v[k]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) index[k] |= (v[k][i] > 0.0) ? (1 << i) : 0;
@@ -609,7 +623,8 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
         if (ci >= d.ncells) continue;
         unsigned char c8 = 0;
         if (index[k] != 0 && index[k] != 255) {
-            const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+            int x, y, z;
+            mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
             int ntri = 0, info = -1;
             const int row = mc_resolve(lut, v[k], index[k], ntri);
             if (row >= 0 && ntri > 0) {
@@ -766,7 +781,8 @@ __device__ __forceinline__ void mc_vertices_one(const float *__restrict__ vol, c
                                                 unsigned long long off, const int32_t *__restrict__ cinfo, int32_t *__restrict__ edge_vid,
                                                 float *__restrict__ verts, float *__restrict__ normals, float *__restrict__ values, int64_t cap_v) {
     const int row = info & 0xffff, ntri = info >> 16;
-    const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+    int x, y, z;
+            mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
     const unsigned owned = mc_owned_mask(x, y, z);
     unsigned seen = 0;
     int64_t vid = (int64_t)(off >> 32);
@@ -858,7 +874,8 @@ __global__ __launch_bounds__(256) void mc_faces_kernel(McDims d, const int32_t *
         const int64_t ci = wg0 + queue[q];
         const int info = cinfo[ci];
         const int row = info & 0xffff, ntri = info >> 16;
-        const int x = (int)(ci % d.c2), y = (int)((ci / d.c2) % d.c1), z = (int)(ci / ((int64_t)d.c1 * d.c2));
+        int x, y, z;
+            mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
         const int64_t t0 = (int64_t)(qoff[q] & 0xffffffffull);
         for (int k = 0; k < ntri * 3; ++k) {
             const int64_t f = t0 + k / 3;
@@ -873,7 +890,8 @@ __device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const
                                             const int8_t *lut, int64_t t, int64_t vid, float *__restrict__ normals, float *__restrict__ values) {
     const int j = (int)(t & 3);
     const int64_t vx = t >> 2;
-    const int x = (int)(vx % d.n2), y = (int)((vx / d.n2) % d.n1), z = (int)(vx / ((int64_t)d.n1 * d.n2));
+    int x, y, z;
+    mc_unflatten(vx, d.n1, d.n2, d.nvox, x, y, z);
     // local edge id seen from the adjacent cell at offset (-a,-b) in the two transverse axes, a = fast transverse axis
     //   x-edge: transverse (y,z): e(a,b) = {0,2,4,6}[a + 2b] ; y-edge: transverse (x,z): {3,1,7,5} ; z-edge: (x,y): {8,9,11,10}
     // (packed 4 bits per entry [j][a + 2b]: a table in memory is not needed)
