@@ -828,7 +828,10 @@ def main():
             workload = (f"full conv_implicit_wnf pipeline, batch={args.batch}/GPU, {args.points}-pt clouds, {args.grid}^3 feature volume ({args.reduce}), "
                         f"{args.volume_size}^3 WNF + GGM + MC33 + surface decode; input: {input_note}"
                         + (f" ({occupancy['occupied_cells_per_garment']:.0f} occupied cells per garment)" if occupancy else ""))
-            traffic = (None, "--no-pmc") if args.no_pmc else measure_traffic(args)
+            if args.no_pmc or world > 1:          # (the counter passes are a single-GPU measurement: at N > 1 the line carries null)
+                traffic = (None, "--no-pmc" if args.no_pmc else "not collected at N > 1 (single-GPU measurement: run bench.py --gpus 1)")
+            else:
+                traffic = measure_traffic(args)
             roofline = conv_roofline(args, groups, args.conv_mode, hw_passes.get("headline"), traffic)
         line = {
             "metric": metric, "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
