@@ -1,0 +1,34 @@
+"""dev-only: the non-default shapes the limits table of DESIGN.md 8 lists, timed -- the decoder with the reference's CLASS-default widths
+(networks/conv_implicit_wnf.py:122: nn_channels=(128, 512, 512, 1); the shipped config uses (128, 256, 256, 1)) goes through the fused fp32-MFMA decoder
+kernel (gn_implicit_decode), not the split-operand one; an edge MLP gn_sa_fused is not instantiated for goes through the unfused chain."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from garmentnets_amd import arith as AR, ops, synthetic as S
+from garmentnets_amd.networks.conv_implicit_wnf import ImplicitWNFDecoder
+from garmentnets_amd.components.pointnet2 import SAModule, Segments
+from garmentnets_amd.components.mlp import MLP
+dev = 'cuda'
+torch.manual_seed(0)
+def timed(f, reps=5):
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); [f() for _ in range(reps)]; e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+vol = torch.randn(1, 128, 64, 64, 64, device=dev).relu()
+q = torch.rand(1, 2 ** 21, 3, device=dev)
+for ch in ((128, 256, 256, 1), (128, 512, 512, 1)):
+    dec = ImplicitWNFDecoder(nn_channels=ch).to(dev).eval().requires_grad_(False)
+    for name, ar in (("f16x2", AR.Arith.named("f16x2", "f16x2")), ("fp32", AR.Arith.named("fp32", "fp32"))):
+        with torch.no_grad():
+            ms = timed(lambda: dec(vol, q, arith=ar))
+        fl = 2.0 * (ch[0] * ch[1] + ch[1] * ch[2] + ch[2] * ch[3]) * q.shape[1]
+        print(f"decoder {ch} {name}: {ms:.3f} ms per 2^21 queries (sampler included), {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+# set abstraction with a non-shipped edge MLP [3+3, 32, 64, 128] (unfused chain) next to the shipped one (fused kernel)
+x, pos, batch = S.synthetic_cloud(16, 6000, seed=1)
+x, pos = x.to(dev), pos.to(dev)
+seg = Segments([6000] * 16, dev)
+for dims in ([6, 64, 64, 128], [6, 32, 64, 128]):
+    sa = SAModule(0.5, 0.05, MLP(dims, batch_norm=True)).to(dev).eval().requires_grad_(False)
+    with torch.no_grad():
+        ms = timed(lambda: sa(x, pos, seg))
+    print(f"SAModule edge MLP {dims}: {ms:.3f} ms per 16 x 6000 points (fps + ball query + PointConv)", flush=True)
