@@ -628,7 +628,7 @@ def main():
             return res
         prev = None
         for k in range(n):
-            d = host_data.to(dev, non_blocking=True) if fn is step_host_io else data
+            d = host_data if fn is step_host_io else data       # a host batch is copied by the job itself, on its front stream
             job = PredictJob(model, d, args.volume_size, 0.5, 0.5, "ascent")
             if prev is not None:
                 res = prev.finish(host=fn is step_host_io)
@@ -870,9 +870,9 @@ def main():
         if in_flight is not None:
             tq = max(r[5] for r in per_rank)
             line["two_in_flight"] = {"value": garments / tq, "unit": "garments/s", "ms_per_step": 1e3 * tq / args.steps, "steps": args.steps,
-                                     "what": "the same K batches through predict.PredictJob: batch k+1's PointNet++ / UNet / lattice is queued before batch "
-                                             "k's tail (vertex counts to the host, mesh slices, surface decode; on its own stream) is finished.  Bit-equal "
-                                             "results (tests/test_gpu_api.py)"}
+                                     "what": "the same K batches through predict.PredictJob: batch k+1's dense path is queued before batch k's tail (vertex counts to "
+                                             "the host, mesh slices, surface decode; on its own stream) is finished, and batch k+1's PointNet++ (serial farthest-point "
+                                             "sampling) runs on a front stream beside batch k's UNet.  Bit-equal results (tests/test_gpu_api.py)"}
         if in_flight_io is not None:
             tqh = max(r[7] for r in per_rank)
             line["two_in_flight_with_host_io"] = {

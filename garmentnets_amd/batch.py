@@ -35,6 +35,12 @@ class Batch:
         for k in self.keys:
             v = getattr(self, k)
             setattr(out, k, v.to(device, **kw) if torch.is_tensor(v) else v)
+        dev = torch.device(device)
+        if dev.type == "cuda" and torch.cuda.is_available():
+            # when the copies were queued: a consumer on ANOTHER stream (predict.PredictJob's front stream) waits for this event instead of
+            # for everything the producing stream has queued since
+            out._ready = torch.cuda.Event()
+            out._ready.record(torch.cuda.current_stream(dev))
         return out
 
     def __repr__(self):

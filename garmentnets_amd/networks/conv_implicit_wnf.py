@@ -83,7 +83,10 @@ class VolumeFeatureAggregator(nn.Module):
         if pre is not None and torch.cuda.is_current_stream_capturing():
             pre = None                                # a captured graph must own its memset: never bake "already zero" into it
         if pre is not None and pre[0] == B and pre[1].shape[-1] == feats.shape[1] and pre[1].device == feats.device:
-            torch.cuda.current_stream(feats.device).wait_event(pre[3])
+            cur = torch.cuda.current_stream(feats.device)
+            cur.wait_event(pre[3])
+            pre[1].record_stream(cur)                 # filled on the side stream, consumed (and outlived) by work on this one: the allocator
+            pre[2].record_stream(cur)                 # must not hand the block to the side stream's NEXT fill while that work is in flight
             prezeroed = (pre[1], pre[2])
         vol, stats = ops.grid_scatter(feats, flat, B, self.grid_shape, self.reduce_method, with_stats=True, prezeroed=prezeroed)   # [B][G][G][G][C]
         out = vol.permute(0, 4, 1, 2, 3)

@@ -110,12 +110,51 @@ def predict_batch(model, batch, volume_size=128, iso_surface_level=0.5, gradient
     return results
 
 
-def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, arith):
+def _record_stream(obj, stream):
+    """every CUDA tensor reachable from obj (tensor / dict / list / Batch) was allocated on another stream and is about to be used on `stream`"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+    elif isinstance(obj, Batch):
+        for k in obj.keys:
+            _record_stream(getattr(obj, k), stream)
+
+
+def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, auto_level, arith, front=None, device=None):
     """everything that needs no host synchronisation, queued on the current stream: PointNet++ -> gridding + UNet -> WNF lattice ->
-    (fixed level) GGM / MC33 of the whole batch -> the batch's grip-point post-processing.  -> state dict for _tail_phase"""
+    (fixed level) GGM / MC33 of the whole batch -> the batch's grip-point post-processing.  -> state dict for _tail_phase.
+    front: a second stream for the batch's FRONT -- the H2D copy of a host batch and PointNet++ (serial farthest-point sampling: 16
+    workgroups for 3 ms, a few small GEMMs) run there, i.e. beside whatever the current stream still has queued (the previous batch's UNet);
+    the current stream joins at the gridding.  The batch's tensors must be ready for the front stream: a host batch is copied on it, a device
+    batch made by Batch.to() carries its own readiness event, anything else is ordered behind the current stream (correct, no overlap)"""
     with torch.no_grad():
         try:
-            pointnet2_result = model.pointnet2_forward(batch, prefetch_volume=True)
+            if front is None:
+                if not batch.pos.is_cuda:
+                    batch = batch.to(device, non_blocking=True)
+                pointnet2_result = model.pointnet2_forward(batch, prefetch_volume=True)
+            else:
+                cur = torch.cuda.current_stream(device)
+                ready = getattr(batch, "_ready", None) if batch.pos.is_cuda else None
+                if batch.pos.is_cuda and ready is None:
+                    front.wait_stream(cur)
+                elif ready is not None:
+                    front.wait_event(ready)
+                with torch.cuda.stream(front):
+                    if not batch.pos.is_cuda:
+                        batch = batch.to(device, non_blocking=True)
+                    pointnet2_result = model.pointnet2_forward(batch, prefetch_volume=True)
+                    done = torch.cuda.Event()
+                    done.record(front)
+                cur.wait_event(done)
+                _record_stream(pointnet2_result, cur)            # allocated on the front stream, consumed from here on
+                _record_stream(batch, cur)
             unet3d_result = model.unet3d_forward(pointnet2_result, arith)
         finally:
             model.volume_agg.drop_prefetch()
@@ -139,7 +178,7 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
             grip_idx = torch.argmin(torch.norm(batch.pos.view(B, sizes[0], 3), dim=2), dim=1) + torch.arange(B, device=batch.pos.device) * sizes[0]
             grip_nocs = nocs_data.pos[grip_idx]
         return dict(pointnet2_result=pointnet2_result, unet3d_result=unet3d_result, wnf_all=wnf_all, job=job, bad=bad,
-                    grip_global=grip_global, conf_global=conf_global, grip_nocs=grip_nocs)
+                    grip_global=grip_global, conf_global=conf_global, grip_nocs=grip_nocs, batch=batch)
 
 
 def _tail_phase(model, batch, st, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction, auto_level, stop_on_nan, arith):
@@ -221,9 +260,9 @@ def _predict_batch_once(model, batch, volume_size, iso_surface_level, gradient_s
 _TAIL = threading.local()         # per host thread: {device: its tail stream} -- two threads driving PredictJobs never share one
 
 
-def _tail_stream(device):
+def _tail_stream(device, kind="tail"):
     streams = _TAIL.__dict__.setdefault("streams", {})
-    key = str(device)
+    key = (kind, str(device))
     if key not in streams:
         streams[key] = torch.cuda.Stream(device=device)
     return streams[key]
@@ -239,13 +278,18 @@ class PredictJob:
     Same results as predict_batch, bit for bit (tests/test_gpu_api.py)."""
 
     def __init__(self, model, batch, volume_size=128, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent",
-                 use_hole_prediction=False, arith=None):
-        self.model, self.batch = model, batch
+                 use_hole_prediction=False, arith=None, front_stream=True):
+        """batch: on the device, or on the HOST (pinned for a truly asynchronous copy) -- the job then copies it itself, on its front stream.
+        front_stream: run the batch's copy + PointNet++ on a second stream, beside the previous batch's UNet (see _dense_phase)"""
+        self.model = model
         self.args = (volume_size, iso_surface_level, gradient_sigma, gradient_direction, use_hole_prediction)
         self.arith = arith or model.arith
-        self.device = batch.pos.device
+        self.device = batch.pos.device if batch.pos.is_cuda else model.device
         self.main = torch.cuda.current_stream(self.device)
-        self.state = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, False, self.arith)
+        front = _tail_stream(self.device, "front") if front_stream else None
+        self.state = _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, gradient_direction, False, self.arith, front=front,
+                                  device=self.device)
+        self.batch = self.state["batch"]            # (the device copy of a host batch)
         self.ready = torch.cuda.Event()
         self.ready.record(self.main)
 
