@@ -391,3 +391,32 @@ def test_dataset_subset_indices(tmp_path):
     assert all(i ^ 1 in set(te.tolist()) for i in te.tolist())               # both samples of an instance
     with pytest.raises(KeyError):
         ds.subset_indices("everything")
+
+
+def test_planted_wnf_checkpoint_gives_a_garment_like_level_set():
+    """synthetic.plant_wnf_path (bench.py's default checkpoint): same 222-tensor schema and shapes as the un-planted one, only carrier rows /
+    the WNF decoder touched, and -- through the CPU oracle at a small grid -- a WNF that is ~0.1 away from the garment, straddles the 0.5 level
+    and gives a compact, smooth shell (thousands of vertices at 64^3)"""
+    from garmentnets_amd import synthetic as S
+    from oracle import pipeline as P
+    hp = S.default_hparams(grid=32, reduce_method="mean")
+    base = S.synthetic_state_dict(hp, 0, planted_nocs=True)
+    sd = S.synthetic_state_dict(hp, 0, planted_nocs=True, planted_wnf=True)
+    assert list(sd) == list(base) and all(sd[k].shape == base[k].shape and sd[k].dtype == base[k].dtype for k in sd)
+    changed = [k for k in sd if not torch.equal(sd[k], base[k])]
+    assert changed and all(k.startswith(("unet_3d.", "volume_agg.local_nn.", "volume_decoder.mlp.")) for k in changed)
+    assert all(torch.equal(sd[k], base[k]) for k in sd if k.startswith(("pointnet2_nocs.", "surface_decoder.")))
+    w = sd["unet_3d.abstract_3d_unet.encoders.0.basic_module.SingleConv1.conv.weight"]
+    assert torch.equal(w[16:], base["unet_3d.abstract_3d_unet.encoders.0.basic_module.SingleConv1.conv.weight"][16:])     # the random rows stay
+    assert float(w[:16, 16:].abs().max()) == 0.0 and torch.allclose(w[:16, :16], torch.full((16, 16, 3, 3, 3), 1.0 / (27 * 16)))
+    x, pos, batch = S.synthetic_cloud(1, 6000, seed=20260928, colour="position")
+    with torch.no_grad():
+        p2 = P.pointnet2_forward(sd, hp, x, pos, batch)
+        vol = P.unet3d(sd, hp["unet3d_params"], P.volume_agg(sd, hp["volume_agg_params"], p2["nocs_data"], 1))
+        wnf = P.decode_volume(sd, vol, 64).numpy()
+    assert wnf.min() < 0.2 and wnf.max() > 1.0 and 0.02 < (wnf > 0.5).mean() < 0.4
+    iso = P.isosurface(wnf, 0.5, 0.5)
+    assert 3000 < len(iso["verts"]) < 25000, len(iso["verts"])           # (x4 at 128^3: 48 k measured on the benchmark batch)
+    # smooth: next to the surface the field changes by less than the level per voxel (a sponge of random-weight noise does not)
+    g = np.abs(np.diff(wnf, axis=0))[(wnf[:-1] > 0.3) & (wnf[:-1] < 0.7)]
+    assert g.size > 100 and np.median(g) < 0.5
