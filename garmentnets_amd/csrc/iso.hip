@@ -589,7 +589,9 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
     __shared__ unsigned long long wsum_c[4];
     vol += blockIdx.y * d.nvox; cinfo += blockIdx.y * d.s_cinfo; cnt8 += blockIdx.y * d.s_cnt; bsum += blockIdx.y * d.s_bsum;
     const int64_t wg0 = (int64_t)blockIdx.x * SCAN_ELEMS;
-    double v[4][8];
+    // pass 1: the sign index of this thread's four cells only -- corner > level in double ((double)p - level > 0  <=>  (double)p > level, exactly);
+    // the eight fp64 corner values are formed again, in pass 2, for the few per cent of the cells the surface crosses: 4 index registers
+    // per thread across the workgroup vote instead of 64 fp64 ones
     int index[4];
     bool any = false;
 #pragma unroll
@@ -599,9 +601,11 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
         if (ci < d.ncells) {
             int x, y, z;
             mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
-            mc_load_cell(vol, d, x, y, z, level, v[k]);
+            const float *p = vol + ((int64_t)z * d.n1 + y) * d.n2 + x;
+            const int64_t sy = d.n2, sz = (int64_t)d.n1 * d.n2;
+            const float c[8] = {p[0], p[1], p[sy + 1], p[sy], p[sz], p[sz + 1], p[sz + sy + 1], p[sz + sy]};     // Lewiner numbering
 #pragma unroll
-            for (int i = 0; i < 8; ++i) index[k] |= (v[k][i] > 0.0) ? (1 << i) : 0;
+            for (int i = 0; i < 8; ++i) index[k] |= ((double)c[i] > level) ? (1 << i) : 0;
         }
         any |= index[k] != 0 && index[k] != 255;
     }
@@ -625,8 +629,10 @@ __global__ __launch_bounds__(256) void mc_classify_kernel(const float *__restric
         if (index[k] != 0 && index[k] != 255) {
             int x, y, z;
             mc_unflatten(ci, d.c1, d.c2, d.ncells, x, y, z);
+            double v[8];
+            mc_load_cell(vol, d, x, y, z, level, v);
             int ntri = 0, info = -1;
-            const int row = mc_resolve(lut, v[k], index[k], ntri);
+            const int row = mc_resolve(lut, v, index[k], ntri);
             if (row >= 0 && ntri > 0) {
                 unsigned used = 0;
                 for (int q = 0; q < ntri * 3; ++q) used |= 1u << lut[row + q];
