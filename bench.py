@@ -16,7 +16,13 @@ timings (RCCL).  Rank 0 prints ONE JSON line:
                         over ranks) -- the default arithmetic (f16x2 operand split for the 3x3x3 convs and the decoder MLPs)
   strict_fp32           the same K steps with --conv-mode fp32 --decode-mode fp32 (v_mfma_f32_32x32x2_f32 everywhere), own roofline
   with_host_io          the same K steps including the H2D copy of the clouds and the D2H copy of every mesh (predict.to_host): the
-                        metric as SURVEY.md 8d words it
+                        metric as SURVEY.md 8d words it, one batch at a time
+  two_in_flight         the same K batches through predict.PredictJob (batch k+1's dense path queued before batch k's tail is finished,
+                        its PointNet++ on a front stream beside batch k's UNet); two_in_flight_with_host_io: the same with the host
+                        copies inside the timed region (the host batch copied on the front stream, the meshes on the tail stream) --
+                        SURVEY.md 8d's metric as the library would run it; `fraction_of_headline` says what the copies cost
+  hbm_members.roofs     fp64 FMA rate and LDS read rate measured on this box (tools/dev/roof_burn): the ceilings the fp64 members of the tail
+                        (GGM, marching cubes) are quoted against next to the HBM fraction
   roofline              dominant kernel by time: launches bracketed with HIP events on the launch stream during the timed steps,
                         labelled with the kernel variant the C ABI reports having launched (gn_last_kernel), achieved = algorithmic
                         FLOPs (54*Cin*Cout per voxel) / time.  The kernel runs at the socket's power cap, so the line carries the
