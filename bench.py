@@ -165,7 +165,13 @@ class KernelTimer:
             vox = float(B) * D * H * W
             return _lib.load().gn_last_kernel().decode(), 54.0 * cin * prep.cout * vox, (cin + prep.cout) * 4.0 * vox + float(prep.pack.numel())
 
+        def describe_w(res_, src, a, d, wp, cout, *rest, **kw):     # Winograd form of the 128-wide kernel: quoted in the DIRECT form's FLOPs (54 Cin Cout per voxel)
+            B, D, H, W, cin = src.shape
+            vox = float(B) * D * H * W
+            return _lib.load().gn_last_kernel().decode(), 54.0 * cin * cout * vox, (cin + cout) * 4.0 * vox + wp.tensor.numel() * 2.0
+
         ops.conv3d_gcr = self._wrap(ops.conv3d_gcr, describe)
+        ops.conv3d_gcr_split_wino = self._wrap(ops.conv3d_gcr_split_wino, describe_w)
         ops.conv3d_gcr_split_persample = self._wrap(ops.conv3d_gcr_split_persample, describe_ps)
         ops.conv3d_gcr_split = self._wrap(ops.conv3d_gcr_split, describe)
         ops.upconv_partial = self._wrap(ops.upconv_partial, describe_up)
@@ -216,6 +222,42 @@ class KernelTimer:
 
 GGM_FP64_INSTR_PER_VOXEL = 120.0     # 9 five-tap symmetric correlations (7 fp64 instructions + 5 fp32->fp64 conversions each) + squares, sums, sqrt
 GGM_LDS_BYTES_PER_VOXEL = 59 * 4.0   # sliding-window reads + inter-pass writes of the fused kernel (csrc/iso.hip ggm_fused_kernel)
+
+
+def fp32_twin_accounting(step):
+    """One untimed step with ops.implicit_decode observed.  The f16x2 decoder kernels are followed by a GATED launch of their fp32 twin
+    (ops.implicit_decode(run_if=flag)): a no-op unless gn_decoder_input_scale marked the garment unsafe for fp16 planes (csrc/decode_split.hip).
+    -> per decoder (by output width): gated launches per step, how many of them ran, how many distinct garments were flagged -- read from the
+    device flags after the step, outside every timed region; plus fp32 decoder launches that were not gated at all."""
+    from garmentnets_amd import ops
+    calls = []
+    orig = ops.implicit_decode
+
+    def spy(vol_b, layers, *a, **kw):
+        calls.append((kw.get("run_if"), int(layers[2][4])))
+        return orig(vol_b, layers, *a, **kw)
+    ops.implicit_decode = spy
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        ops.implicit_decode = orig
+    per, ungated = {}, 0
+    for flag, outc in calls:
+        if flag is None:
+            ungated += 1
+            continue
+        d = per.setdefault(f"out{outc}", {"gated_launches_per_step": 0, "ran": 0, "_garments": set()})
+        d["gated_launches_per_step"] += 1
+        if float(flag.reshape(-1)[0]) != 0.0:
+            d["ran"] += 1
+            d["_garments"].add(flag.data_ptr())
+    for d in per.values():
+        d["garments_on_the_fp32_twin"] = len(d.pop("_garments"))
+    return {"decoders": per, "ungated_fp32_decoder_launches_per_step": ungated,
+            "what": "gated launches of the fp32 decoder kernel behind every f16x2 decoder launch (implicit_decode_kernel<OUT>): `ran` of them did work "
+                    "(the device-side `unsafe` flag of gn_decoder_input_scale), the others return after reading the flag.  In a kernel trace their "
+                    "duration is queue residency: beside a batch in flight on another stream a no-op launch waits for a free CU like any other"}
 
 
 def measured_roofs():
@@ -781,6 +823,10 @@ def main():
         hbm_members = hbm.summary(wnf_all, lvl)
         del p2, u3, wnf_all, job, meshes
 
+    fp32_twin = None
+    if rank == 0 and args.workload == "full" and args.decode_mode == "f16x2":
+        fp32_twin = fp32_twin_accounting(step)
+
     validation = None
     if rank == 0 and not args.no_validate:
         validation = validate(model, args, dev, auto_level[0])
@@ -873,6 +919,8 @@ def main():
         }
         if hbm_members is not None:
             line["hbm_members"] = hbm_members
+        if fp32_twin is not None:
+            line["fp32_twin"] = fp32_twin
         if in_flight is not None:
             tq = max(r[5] for r in per_rank)
             line["two_in_flight"] = {"value": garments / tq, "unit": "garments/s", "ms_per_step": 1e3 * tq / args.steps, "steps": args.steps,

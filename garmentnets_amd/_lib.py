@@ -43,6 +43,9 @@ PROTOTYPES = {
     "gn_conv_affine_pack_bytes": [_i32, _i32, _i32],
     "gn_conv_affine_pack": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "gn_conv3d_gcr_split_persample": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _sz, _vp],
+    "gn_conv_affine_pack_wino_bytes": [_i32, _i32, _i32],
+    "gn_conv_affine_pack_wino": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "gn_conv3d_gcr_split_wino": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
     "gn_upconv_partial": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_grid_tile_flags": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
@@ -71,7 +74,7 @@ PROTOTYPES = {
     "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
-_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_conv3d_occupancy_workspace_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz, "gn_mesh_largest_component_workspace_bytes": _sz}
+_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_conv_affine_pack_wino_bytes": _sz, "gn_conv3d_occupancy_workspace_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz, "gn_mesh_largest_component_workspace_bytes": _sz}
 
 _lib = None
 

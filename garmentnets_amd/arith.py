@@ -17,6 +17,9 @@ global mutable state except immutable LUTs).  ``DEFAULT`` is read from the envir
     affine_in_weights  (f16x2) the first two encoder convolutions -- whose input is at rest outside the occupied cells' neighbourhood -- take
                        the GroupNorm affine in per-sample weights + a bias table, so the matrix cores multiply exact zeros there: same MACs,
                        less power, more clock under the socket cap (csrc/conv_prep.hip).  fp32-class like f16x2 itself
+    winograd           (f16x2) the 128-wide convolutions over one full-resolution source -- above all the first encoder convolution, 128 -> 128 at 128^3 --
+                       run in Winograd F(2,3) form along x: 36 instead of 54 matrix-core tap products per output pair (csrc/unet_wino.hip); the transforms
+                       are exact in the operands' zero pattern, error against fp64 stays within the f16x2 contract (tests/test_gpu_parity.py)
     polyphase_upconv   polyphase form of the decoders' first convolutions (csrc/upconv.hip)
     fold_final_conv    the decoders absorb the UNet's final 1x1x1 convolution into their first layer (conv_implicit_wnf.UNetResult)
     fused_lattice      lattice queries sampled INSIDE the decoder-MLP kernel (gn_implicit_decode_lattice_split, no sampled-row buffer in
@@ -48,6 +51,7 @@ class Arith:
     decode_mode: str = "f16x2"
     sparse_first_conv: bool = True
     affine_in_weights: bool = True
+    winograd: bool = False
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
     fused_lattice: bool = False
@@ -72,7 +76,7 @@ class Arith:
         return cls(conv_mode=CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)],
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
                    sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), affine_in_weights=_env_flag("GARMENTNETS_AFFINE_IN_WEIGHTS"),
-                   polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
+                   winograd=_env_flag("GARMENTNETS_WINOGRAD", False), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
                    fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
 
     def replace(self, **kw):

@@ -38,10 +38,24 @@ class Batch:
         dev = torch.device(device)
         if dev.type == "cuda" and torch.cuda.is_available():
             # when the copies were queued: a consumer on ANOTHER stream (predict.PredictJob's front stream) waits for this event instead of
-            # for everything the producing stream has queued since
-            out._ready = torch.cuda.Event()
-            out._ready.record(torch.cuda.current_stream(dev))
+            # for everything the producing stream has queued since.  The event vouches for the tensors AS THEY ARE NOW: ready_event() hands it
+            # out only while every field still is the same tensor object at the same version (a field re-bound or edited in place after
+            # .to() was produced by later work on the caller's stream -- the consumer then has to order itself behind that stream)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            out._ready = (ev, out._fingerprint())
         return out
+
+    def _fingerprint(self):
+        return tuple((k, id(v), v._version) for k, v in ((k, getattr(self, k)) for k in self.keys) if torch.is_tensor(v))
+
+    def ready_event(self):
+        """the event recorded behind the copies of .to(), or None when a field has been re-bound / modified in place since (or the batch was not
+        made by .to()): the caller must then wait for the producing stream itself"""
+        r = self.__dict__.get("_ready")
+        if r is None or r[1] != self._fingerprint():
+            return None
+        return r[0]
 
     def __repr__(self):
         return "Batch(" + ", ".join(f"{k}={tuple(getattr(self, k).shape) if torch.is_tensor(getattr(self, k)) else getattr(self, k)}" for k in self.keys) + ")"

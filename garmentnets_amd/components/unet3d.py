@@ -22,6 +22,13 @@ def number_of_features_per_level(init_channel_number, num_levels):
     return [init_channel_number * 2 ** k for k in range(num_levels)]
 
 
+def _wino_ok(arith, src0, cout):
+    """the launch would take the 128-wide kernel and fits its Winograd form (arith.winograd; csrc/unet_wino.hip)"""
+    B, D, H, W, cin = src0.shape
+    return (arith.winograd and arith.conv_mode == ops.SPLIT_F16X2 and ops.wino_supported(cin, cout, (D, H, W))
+            and (D // 4) * (H // 8) * (W // 8) * (cout // 128) * B >= 512)
+
+
 class SingleConv(PackedModule, nn.Sequential):
     """'gcr' block: GroupNorm(num_groups, Cin) -> Conv3d(Cin, Cout, 3, pad 1, no bias) -> ReLU."""
 
@@ -107,6 +114,10 @@ class SingleConv(PackedModule, nn.Sequential):
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)
                 return r if with_stats else (r, None)
+            if src1 is None and not sp and _wino_ok(arith, src0, cout):
+                wwino = cache.get(gen, "wino", lambda: ops.pack_conv_weight_split_wino(self.conv.weight).to(self.conv.weight.device))
+                r = ops.conv3d_gcr_split_wino(src0, a, d, wwino, cout, relu=True, with_stats=with_stats, act_inv=act_inv)
+                return r if with_stats else (r, None)
             r = ops.conv3d_gcr_split(src0, src1, a, d, wpack, cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
             return r if with_stats else (r, None)
         a, d = ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, gamma, beta)
@@ -123,7 +134,9 @@ class SingleConv(PackedModule, nn.Sequential):
         w = self.conv.weight
         if not w.is_contiguous():
             w = w.contiguous()
-        prep = ops.conv_affine_pack(w, a, d, st0, sparse.get("rest_in") if reach > 1 else None)
+        rest = sparse.get("rest_in") if reach > 1 else None
+        wino = _wino_ok(arith, src0, cout)
+        prep = ops.conv_affine_pack(w, a, d, st0, rest, wino=wino)
         # away from the cells the operand is zero: the output is ReLU(0 * scale + K[interior]) = ReLU(K[63]) -- the next layer's rest value
         sparse["rest_out"] = torch.relu(prep.kbias[:, 63]).contiguous()
         sp = {}
@@ -133,7 +146,9 @@ class SingleConv(PackedModule, nn.Sequential):
             if small_in is None:
                 small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
             ncls = (2 * reach + 1) ** 3
-            small_out = ops.conv3d_gcr_split_persample(small_in, prep, relu=True)                                         # (a plain dense launch)
+            # (a plain dense launch; the Winograd pack cannot serve a 5^3 volume: the class constants come from the direct form's pack -- away from
+            #  the cells the operand is exactly zero in either form, so they are the same numbers)
+            small_out = ops.conv3d_gcr_split_persample(small_in, ops.conv_affine_pack(w, a, d, st0, rest) if wino else prep, relu=True)
             step = 2 if reach == 1 else 1
             kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
             sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)

@@ -344,6 +344,44 @@ def pack_conv_weight_split(w, mode):
     return SplitPack(pk.contiguous().view(torch.int16), mode, (1.0 / scale).contiguous().to(w.device))
 
 
+def wino_supported(cin, cout, dims):
+    """shapes gn_conv3d_gcr_split_wino takes (csrc/unet_wino.hip): one source, whole 4 x 8 x 8 tiles, 32-bit byte offsets inside a sample"""
+    D, H, W = [int(v) for v in dims]
+    return (cin % 16 == 0 and cin <= 256 and cout % 128 == 0 and D % 4 == 0 and H % 8 == 0 and W % 8 == 0 and D * H * W <= (1 << 27)
+            and D * H * W * cin * 4 < (1 << 32))
+
+
+def pack_conv_weight_split_wino(w):
+    """(Cout, Cin, 3,3,3) fp32 -> the Winograd F(2,3)-along-x pack of gn_conv3d_gcr_split_wino (csrc/unet_wino.hip): per (kd, kh, channel) the three
+    kw taps g0 g1 g2 become the four transform positions (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2), in fp64; per-output-channel power-of-two
+    scale over the TRANSFORMED row (row maximum in [1, 2)), two fp16 planes, fragment order [Cin/16][36 steps = (j * 3 + kd) * 3 + kh][Cout/32][plane]
+    [h 2][r 32][8] + six zero steps (the kernel's fragment DMA runs two groups of three steps ahead)."""
+    cout, cin = w.shape[:2]
+    w = w.detach().double().cpu()
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("jk,nczyk->nczyj", G, w)                                                           # (Cout, Cin, kd, kh, j)
+    m = u.reshape(cout, -1).abs().amax(dim=1)
+    scale = _pow2_floor_inv(m)
+    base = (u * scale.view(cout, 1, 1, 1, 1)).float().permute(4, 2, 3, 1, 0).reshape(36, cin // 16, 2, 8, cout // 32, 32)   # [step][S][h][8][blk][r]
+    base = base.permute(1, 0, 4, 2, 5, 3)                                                               # [S][step][blk][h][r][8]
+    p1 = base.to(torch.float16)
+    p2 = (base - p1.float()).to(torch.float16)
+    pk = torch.stack((p1, p2), dim=3).contiguous().reshape(cin // 16 * 36, -1)                          # [S * step][blk][plane][h][r][8]
+    pk = torch.cat([pk, torch.zeros_like(pk[:6])], dim=0)
+    return SplitPack(pk.contiguous().view(torch.int16), SPLIT_F16X2, (1.0 / scale).float().contiguous())
+
+
+def conv3d_gcr_split_wino(src, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1):
+    """the literal form through the Winograd kernel (pack = pack_conv_weight_split_wino)"""
+    B, D, H, W, C0 = src.shape
+    out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src.device)
+    s, q = _stats_buffers(B, cout, src.device, with_stats)
+    ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src.device)
+    _lib.call("gn_conv3d_gcr_split_wino", _p(src), C0, _p(a), _p(d), _p(pack.tensor), _p(pack.out_scale), _p(act_inv), None, B, D, H, W, cout,
+              1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(ows), ows_bytes, _stream())
+    return (out, (s, q, D * H * W)) if with_stats else out
+
+
 def grid_tile_flags(flat_idx, B, grid_shape, reach=1):
     """uint8 [B][tiles]: the 4 x 8 x 8 output tiles of a 3x3x3 conv over the scattered volume that can see an occupied cell (reach 1),
     or of the conv behind it (reach 2)"""
@@ -430,13 +468,13 @@ def conv3d_gcr_split(src0, src1, a, d, pack, cout, relu=True, with_stats=False, 
 class AffinePack:
     """what gn_conv_affine_pack prepared for ONE batch of one 'gcr' layer: per-sample fp16x2 weight sets with the GroupNorm affine folded
     in, the staging affine (s, -c s), the output scales and the border-class bias table"""
-    __slots__ = ("pack", "stage_a", "stage_d", "out_scale", "kbias", "cin", "cout")
+    __slots__ = ("pack", "stage_a", "stage_d", "out_scale", "kbias", "cin", "cout", "wino")
 
 
-def conv_affine_pack(weight, a, d, stats, rest=None):
+def conv_affine_pack(weight, a, d, stats, rest=None, wino=False):
     """weight: the raw Conv3d weight [Cout][Cin][3][3][3] (fp32, device); a, d [B][Cin]: the GroupNorm affine (groupnorm_affine without the
     sample scale); stats = (sum, sumsq, V) of the layer's input; rest [B][Cin] or None (zeros): the value the input holds away from its
-    support -> AffinePack (csrc/conv_prep.hip)"""
+    support -> AffinePack (csrc/conv_prep.hip).  wino: the pack holds the Winograd F(2,3)-along-x transformed weights (csrc/unet_wino.hip)"""
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     B, dev = a.shape[0], a.device
     w = weight.detach()
@@ -445,18 +483,19 @@ def conv_affine_pack(weight, a, d, stats, rest=None):
     if rest is not None:
         _chk(rest, torch.float32, "rest")
         assert tuple(rest.shape) == (B, cin)
-    nbytes = _lib.load().gn_conv_affine_pack_bytes(B, cin, cout)
+    sfx = "_wino" if wino else ""
+    nbytes = getattr(_lib.load(), "gn_conv_affine_pack" + sfx + "_bytes")(B, cin, cout)
     if nbytes == 0 and B > 0:
         raise ValueError("conv_affine_pack: channel counts must be multiples of 16 (in) / 32 (out)")
     r = AffinePack()
-    r.cin, r.cout = cin, cout
+    r.cin, r.cout, r.wino = cin, cout, bool(wino)
     r.pack = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
     r.stage_a = torch.empty((B, cin), dtype=torch.float32, device=dev)
     r.stage_d = torch.empty((B, cin), dtype=torch.float32, device=dev)
     r.out_scale = torch.empty((B, cout), dtype=torch.float32, device=dev)
     r.kbias = torch.empty((B, 64, cout), dtype=torch.float32, device=dev)
     ws = torch.empty((B * cin * 12 + B * cout * 4 + 16,), dtype=torch.uint8, device=dev)
-    _lib.call("gn_conv_affine_pack", _p(w), cin, cout, _p(a), _p(d), _p(stats[0]), _p(stats[1]), int(stats[2]), _p(rest), B, _p(r.pack), nbytes,
+    _lib.call("gn_conv_affine_pack" + sfx, _p(w), cin, cout, _p(a), _p(d), _p(stats[0]), _p(stats[1]), int(stats[2]), _p(rest), B, _p(r.pack), nbytes,
               _p(r.stage_a), _p(r.stage_d), _p(r.out_scale), _p(r.kbias), _p(ws), ws.numel(), _stream())
     return r
 
@@ -468,6 +507,12 @@ def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_acti
     out = torch.empty((B, D, H, W, prep.cout), dtype=torch.float32, device=src.device)
     s, q = _stats_buffers(B, prep.cout, src.device, with_stats)
     ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src.device)
+    if prep.wino:
+        if partial is not None:
+            raise ValueError("conv3d_gcr_split_persample: the Winograd pack cannot take a polyphase partial")
+        _lib.call("gn_conv3d_gcr_split_wino", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), None, _p(prep.kbias),
+                  B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(ows), ows_bytes, _stream())
+        return (out, (s, q, D * H * W)) if with_stats else out
     _lib.call("gn_conv3d_gcr_split_persample", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), _p(prep.kbias),
               B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(partial), _p(ows), ows_bytes,
               _stream())

@@ -132,7 +132,9 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
     front: a second stream for the batch's FRONT -- the H2D copy of a host batch and PointNet++ (serial farthest-point sampling: 16
     workgroups for 3 ms, a few small GEMMs) run there, i.e. beside whatever the current stream still has queued (the previous batch's UNet);
     the current stream joins at the gridding.  The batch's tensors must be ready for the front stream: a host batch is copied on it, a device
-    batch made by Batch.to() carries its own readiness event, anything else is ordered behind the current stream (correct, no overlap)"""
+    batch made by Batch.to() carries its own readiness event AS LONG AS its fields are untouched since (Batch.ready_event checks object identity and
+    the tensors' version counters), anything else -- incl. a batch whose fields were re-bound or edited in place after .to() -- is ordered behind
+    the current stream (correct, no overlap)"""
     with torch.no_grad():
         try:
             if front is None:
@@ -141,11 +143,14 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
                 pointnet2_result = model.pointnet2_forward(batch, prefetch_volume=True)
             else:
                 cur = torch.cuda.current_stream(device)
-                ready = getattr(batch, "_ready", None) if batch.pos.is_cuda else None
+                # (Batch.ready_event: None once a field was re-bound or edited in place after .to() -- that work sits on the caller's stream)
+                ready = batch.ready_event() if (batch.pos.is_cuda and hasattr(batch, "ready_event")) else None
                 if batch.pos.is_cuda and ready is None:
                     front.wait_stream(cur)
                 elif ready is not None:
                     front.wait_event(ready)
+                if batch.pos.is_cuda:
+                    _record_stream(batch, front)                 # allocated on the caller's stream, read on the front stream
                 with torch.cuda.stream(front):
                     if not batch.pos.is_cuda:
                         batch = batch.to(device, non_blocking=True)

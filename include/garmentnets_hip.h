@@ -240,6 +240,28 @@ int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_
                                   double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
                                   const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream);
 
+/* Winograd F(2,3) along x for the 128-wide 'gcr' convolution (csrc/unet_wino.hip; components/unet3d.py:53-76, the shape it exists for:
+ * the first encoder convolution 128 -> 128 at full resolution, components/unet3d.py:127-133): per output pair (x, x+1) and (kd, kh, channel)
+ * FOUR products m0 = (d0 - d2) g0, m1 = (d1 + d2)(g0 + g1 + g2)/2, m2 = (d2 - d1)(g0 - g1 + g2)/2, m3 = (d1 - d3) g2 instead of six --
+ * 36 instead of 54 matrix-core tap products per output pair, GN_SPLIT_F16X2 arithmetic on the transformed operands (input transform in
+ * fp32 before the plane split, weight transform in fp64 on the pack side, output transform in fp32).  Exactly-zero operands stay exactly zero.
+ * ONE entry for both operand forms:
+ *   kbias == NULL: the literal form.  a, d [B][Cin] = gn_groupnorm_affine (with its act_inv_scale [B], or NULL); pack = the transformed
+ *                  static weights [Cin/16][36 steps = (j * 3 + kd) * 3 + kh][Cout/32][2 planes][64 lanes] x 16 B + six zero steps
+ *                  (garmentnets_amd.ops.pack_conv_weight_split_wino); out_scale [Cout].
+ *   kbias != NULL: the affine-in-weights form -- a, d, pack, out_scale [B][Cout], kbias [B][64][Cout] from gn_conv_affine_pack_wino
+ *                  (same contract as gn_conv_affine_pack, 36 steps per slice: gn_conv_affine_pack_wino_bytes); act_inv_scale NULL.
+ * Requirements (GN_EINVAL otherwise): one source, Cin % 16 == 0, Cin <= 256, Cout % 128 == 0, D % 4 == H % 8 == W % 8 == 0,
+ * D*H*W <= 2^27, D*H*W*Cin*4 < 2^32.  tile_active / kconst / kreach / occ_ws as gn_conv3d_gcr_split. */
+size_t gn_conv_affine_pack_wino_bytes(int B, int Cin, int Cout);
+int gn_conv_affine_pack_wino(const float *w, int Cin, int Cout, const float *a, const float *d, const double *sum, const double *sumsq, int64_t V,
+                             const float *coff, int B, void *pack, size_t pack_bytes, float *stage_a, float *stage_d, float *out_scale,
+                             float *kbias, void *ws, size_t ws_bytes, void *stream);
+int gn_conv3d_gcr_split_wino(const float *src, int Cin, const float *a, const float *d, const void *pack, const float *out_scale,
+                             const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                             double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
+                             void *occ_ws, size_t occ_ws_bytes, void *stream);
+
 /* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
  * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27
  * fine taps merge into 8 coarse taps per output parity class (sums of weights, host side, fp64) -- 8/27 of the MACs of those channels,
