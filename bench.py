@@ -100,6 +100,9 @@ def parse():
                     help="arithmetic of the 3x3x3 convs of the HEADLINE pass: f16x2 (default; fp32 operands split into two fp16 planes, fp32 "
                          "accumulation), fp32 (v_mfma_f32_32x32x2_f32), bf16x3, bf16x2 (PREVIEW: does not guarantee the 1e-4 WNF tolerance -- "
                          "0.9-1.2e-4 observed on the G=32 goldens)")
+    ap.add_argument("--winograd", default="on", choices=["on", "off"],
+                    help="on (default): the 128-wide f16x2 convolutions over one full-resolution source -- above all the first encoder convolution -- in Winograd "
+                         "F(2,3) form along x (36 instead of 54 matrix-core tap products per output pair; csrc/unet_wino.hip); off: the direct form everywhere")
     ap.add_argument("--decode-mode", default="f16x2", choices=["f16x2", "fp32"], help="arithmetic of the decoder MLPs of the headline pass")
     ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
                     help="1 (default): one batch at a time (predict.predict_batch, the reference's loop); 2: every timed pass keeps two batches in "
@@ -115,6 +118,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--n1-value", type=float, default=None, help="garments/s of the N=1 run of the same sweep (tools/run_scale.sh passes it): the line "
                                                                    "then carries scaling_vs_n1 = value / (N x n1)")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the single-garment latency at the reference's shipped predict configuration (latency_b1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-garments", type=int, default=1)
     a = ap.parse_args()
@@ -260,6 +264,62 @@ def fp32_twin_accounting(step):
                     "duration is queue residency: beside a batch in flight on another stream a no-op launch waits for a free CU like any other"}
 
 
+def latency_b1(args, dev, runs=21):
+    """ONE garment through predict_batch at the reference's SHIPPED predict configuration (config/predict_default.yaml:5,43 + predict.py:62: batch 1,
+    32^3 feature volume with max reduction, 128^3 WNF lattice -- what `python -m garmentnets_amd.predict` defaults to), library-default arithmetic:
+    median wall time of `runs` synchronised runs, and the stage split of one more run (HIP events).  Every throughput figure of the line is a
+    batch of 16 or 8; here the serial farthest-point sampling (one workgroup per garment) and the launch gaps are what is left."""
+    from garmentnets_amd.arith import Arith
+    from garmentnets_amd.batch import Batch
+    from garmentnets_amd.common import marching_cubes_util as mcu
+    from garmentnets_amd.networks.conv_implicit_wnf import ConvImplicitWNFPipeline
+    from garmentnets_amd.predict import _iso_capacity, predict_batch
+    hp, sd, shard, _ = bench_inputs(1, args.points, 32, "max", args.input)
+    model = ConvImplicitWNFPipeline(**hp)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().requires_grad_(False)
+    model.arith = Arith.named("f16x2", "f16x2")
+    data = Batch(sizes=shard.sizes, x=shard.x, pos=shard.pos, batch=shard.batch).to(dev)
+    Q = 128
+    run = lambda: predict_batch(model, data, volume_size=Q, iso_surface_level=0.5, gradient_sigma=0.5, gradient_direction="ascent")
+    res = None
+    for _ in range(3):
+        res = run()
+    torch.cuda.synchronize()
+    if any(bool(torch.isnan(r["verts"]).any()) for r in res):
+        return {"skipped": "the synthetic checkpoint's WNF does not straddle the 0.5 level at G = 32"}
+    ts = []
+    for _ in range(runs):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    ts.sort()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    with torch.no_grad():
+        ev[0].record()
+        p2 = model.pointnet2_forward(data, prefetch_volume=True)
+        ev[1].record()
+        u3 = model.unet3d_forward(p2)
+        ev[2].record()
+        wnf = model.volume_lattice_forward(u3, Q)["pred_volume"]
+        ev[3].record()
+        job = mcu.IsoBatchJob(Q, 0.5, 0.5, "ascent", cap_v=_iso_capacity(model, Q))
+        job.enqueue(wnf)
+        job.finish()
+        q_all = job.padded_queries()
+        if q_all is not None:
+            model.surface_decoder_forward(u3, q_all)
+        ev[4].record()
+        torch.cuda.synchronize()
+    names = ("pointnet2_forward", "unet3d_forward (gridding + UNet)", "volume_lattice_forward (sampler + decoder)", "GGM + MC33 + surface decode")
+    return {"ms_median": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "runs": runs, "garments_per_s": 1e3 / ts[len(ts) // 2],
+            "config": "batch 1, 6000-pt cloud, 32^3 feature volume (max), 128^3 WNF + GGM + MC33 + surface decode: config/predict_default.yaml:5,43, predict.py:62",
+            "verts": int(res[0]["verts"].shape[0]), "stages_ms": {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)},
+            "what": "wall time of predict_batch for ONE garment, inputs resident, results left on the device, host synchronised before and after each run"}
+
+
 def measured_roofs():
     """fp64 vector rate and LDS read rate measured on THIS box by tools/dev/roof_burn (built by __graft_entry__.build()): the ceilings of
     the members whose arithmetic is fp64 by contract (scipy / scikit-image bit-exactness).  -> dict or None"""
@@ -363,7 +423,7 @@ class HbmMembers:
             out["iso_on_shell_volume"] = sh
         roofs = measured_roofs()
         if roofs is not None:
-            out["roofs"] = dict(roofs, public_spec={"fp64_vector_tflops": 78.6, "lds_TBs": "256 CUs x 128 B/clk x 2.4 GHz = 78.6"},
+            out["roofs"] = dict(roofs, public_spec={"fp64_vector_tflops": 78.6, "lds_TBs": "MI355X_MICROARCH.md: ds_read_b128 256 B/clk/CU = 157 TB/s at 2.4 GHz, ~150 measured with every CU streaming"},
                                 note="measured on this box right before this line was printed (tools/dev/roof_burn.hip)")
             instr_rate = roofs["fp64_fma_tflops"] * 1e12 / 2.0          # fp64 vector instructions per second (an FMA counts 2 FLOP)
 
@@ -384,8 +444,10 @@ class HbmMembers:
                         if isinstance(v, dict) and k.startswith("mc_") and "ms" in v:
                             v["ns_per_vertex"] = v["ms"] * 1e6 / nv
         out["note"] = ("one untimed step; bytes = algorithmic (each input / output of the call once); scatter is atomics / latency-bound by nature "
-                       "(6000 points per garment), zero-fill runs on a side stream beside farthest-point sampling; GGM is ONE fused launch whose 9 "
-                       "fp64 5-tap correlations per voxel (scipy's arithmetic, bit for bit) make it fp64-ALU / LDS bound, not HBM bound; the MC33 "
+                       "(6000 points per garment), zero-fill runs on a side stream beside farthest-point sampling; GGM is ONE fused launch at the algorithmic minimum of HBM bytes (one read, one write); its three "
+                       "fractions (frac_of_8TBs, frac_of_fp64_rate, frac_of_lds_rate against the ceilings measured in `roofs`) are ALL small: it is bound by "
+                       "none of the three but by latency / occupancy -- 9 dependent five-tap fp64 chains per voxel (scipy's arithmetic, bit for bit) at the "
+                       "few waves per SIMD its 33 KB tiles allow; the MC33 "
                        "stages do per-cell fp64 case analysis and per-vertex fp64 gathers: their time follows the number of surface cells, not the bytes")
         return out
 
@@ -444,9 +506,14 @@ def conv_roofline(args, groups, conv_mode, hw=None, traffic=None):
         peak, peak_note = PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense peak"
     else:
         n = SPLIT_PRODUCTS[conv_mode]
+        wino = "wino" in key
+        if wino:            # Winograd F(2,3) along x: 36 of the direct form's 54 tap products per output pair (csrc/unet_wino.hip)
+            n = n * 36.0 / 54.0
         peak = PEAK_16BIT_MFMA_TFLOPS / n
-        peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} matrix-core products per algorithmic fp32 product "
-                     f"({conv_mode}); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
+        peak_note = (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n:g} EXECUTED matrix-core products per algorithmic fp32 product "
+                     f"({conv_mode}" + (" x 36/54: Winograd F(2,3) along x; `achieved` counts the DIRECT form's 54*Cin*Cout FLOPs per voxel, so frac is the "
+                                        "matrix pipe's utilisation, and achieved / (2500 / 3) is the speed in the direct form's terms" if wino else "") +
+                     f"); executed {achieved * n:.0f} TFLOP/s; the fp32-MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
     tr, src, tr_detail = None, None, None
     if traffic is not None:
         table, src = traffic
@@ -458,13 +525,15 @@ def conv_roofline(args, groups, conv_mode, hw=None, traffic=None):
             "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"], "flops_per_launch": g["work"] / g["n"],
             "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
             "hbm_frac_of_8TBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "frac_of_direct_form_peak": achieved / (PEAK_16BIT_MFMA_TFLOPS / SPLIT_PRODUCTS[conv_mode]) if conv_mode != "fp32" else None,
             "all_conv_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["work"] / (v["ms"] * 1e-3) / 1e12,
-                                       "frac": v["work"] / (v["ms"] * 1e-3) / 1e12 / peak}
+                                       "frac": v["work"] / (v["ms"] * 1e-3) / 1e12 / (
+                                           PEAK_FP32_MFMA_TFLOPS if conv_mode == "fp32" else PEAK_16BIT_MFMA_TFLOPS / (SPLIT_PRODUCTS[conv_mode] * (36.0 / 54.0 if "wino" in k else 1.0)))}
                                    for k, v in groups.items()}}
     if hw is not None:
         sclk = hw.get("sclk_mhz")
         out.update(sclk_mhz=sclk, socket_power_w=hw.get("socket_power_w"), power_cap_w=hw.get("power_cap_w"),
-                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None,
+                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None, throttle=hw.get("throttle"),
                    clock_note="sclk / socket power: mean of the GPU's hwmon nodes sampled every 50 ms during this pass (all kernels of the step, "
                               "not the dominant one alone); the peak assumes 2400 MHz, frac_at_2400mhz = frac x 2400 / sclk is the matrix-core "
                               "issue rate the kernel sustains per clock; busy counters: profiles/", hwmon=hw)
@@ -646,7 +715,7 @@ def main():
         timer.install_conv()
 
     # the model's arithmetic is a per-model immutable value (garmentnets_amd/arith.py): each pass installs its own
-    headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False)    # dense, occupancy-independent
+    headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False, winograd=args.winograd == "on")    # dense, occupancy-independent
     model.arith = headline
     auto_level = [False]
 
@@ -686,10 +755,11 @@ def main():
         return res
 
     sys.path.insert(0, os.path.join(REPO, "tools"))
-    from power_trace import HwmonSampler
+    from power_trace import HwmonSampler, throttle_read, throttle_window
     hw_passes = {}
 
     def timed(fn, steps, warmup, hw_name=None):
+        thr0 = throttle_read(dev_index) if (hw_name and rank == 0) else None     # (before the warm-up: the GPU goes into the timed steps warm)
         run_steps(fn, warmup)
         torch.cuda.synchronize()
         parallel.barrier()
@@ -708,6 +778,8 @@ def main():
         if sampler is not None:
             sampler.__exit__(None, None, None)
             hw_passes[hw_name] = sampler.summary()
+            # why the clock is what it is: share of the pass (warm-up + timed steps: the same workload) the firmware spent limiting it, per limiter
+            hw_passes[hw_name]["throttle"] = throttle_window(thr0, throttle_read(dev_index))
         timer.enabled = False
         return dt, res, timer.summary()
 
@@ -850,6 +922,10 @@ def main():
         pipelined[0] = False
         torch.cuda.empty_cache()
 
+    lat_b1 = None
+    if rank == 0 and world == 1 and args.workload == "full" and not args.no_latency_b1:
+        lat_b1 = latency_b1(args, dev)
+
     # the only collective: per-rank (garments, seconds of each timed pass) over RCCL/xGMI
     n_local = (hi - lo) * args.steps
     per_rank = parallel.gather_metrics([n_local, dt, strict[0] if strict else 0.0, hostio or 0.0, occupancy["seconds"] if occupancy else 0.0,
@@ -886,7 +962,8 @@ def main():
                 traffic = measure_traffic(args)
             roofline = conv_roofline(args, groups, args.conv_mode, hw_passes.get("headline"), traffic)
         line = {
-            "metric": metric, "value": garments / tmax, "unit": "garments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": garments / tmax, "unit": "garments/s", "input": args.input,
+            "mesh_verts_per_garment": (verts_total / (hi - lo)) if verts_total is not None else None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "input": args.input, "batch_per_gpu": args.batch, "global_batch": global_batch,
@@ -900,7 +977,9 @@ def main():
                        "mesh_verts_per_garment": (verts_total / (hi - lo)) if verts_total is not None else None,
                        "encoder_convs": "dense: every tile through the matrix cores (occupancy-aware launch OFF for the headline)" + (
                            "; GroupNorm affine of the two convolutions behind the scattered volume folded into per-sample weights + a bias table, operand exactly zero in "
-                           "empty cells (Arith.affine_in_weights; the literal form is timed as literal_affine)" if headline.affine_in_weights and args.conv_mode == "f16x2" else ""), "mesh_verts_per_step": verts_total,
+                           "empty cells (Arith.affine_in_weights; the literal form is timed as literal_affine)" if headline.affine_in_weights and args.conv_mode == "f16x2" else "") + (
+                           "; 128-wide convolutions in Winograd F(2,3) form along x (Arith.winograd: 36 of 54 tap products; --winograd off = the direct form)"
+                           if headline.winograd and args.conv_mode == "f16x2" else ""), "mesh_verts_per_step": verts_total,
                        "parallelism": f"dp{world} (independent garment shards, no data-path collective)"},
             "timed_region": "inputs resident in HBM, results left on the device (with_host_io adds H2D of the clouds + D2H of every mesh); K batches "
                             "begun and finished between the two barriers" + (
@@ -921,6 +1000,8 @@ def main():
             line["hbm_members"] = hbm_members
         if fp32_twin is not None:
             line["fp32_twin"] = fp32_twin
+        if lat_b1 is not None:
+            line["latency_b1"] = lat_b1
         if in_flight is not None:
             tq = max(r[5] for r in per_rank)
             line["two_in_flight"] = {"value": garments / tq, "unit": "garments/s", "ms_per_step": 1e3 * tq / args.steps, "steps": args.steps,

@@ -51,7 +51,7 @@ class Arith:
     decode_mode: str = "f16x2"
     sparse_first_conv: bool = True
     affine_in_weights: bool = True
-    winograd: bool = False
+    winograd: bool = True
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
     fused_lattice: bool = False
@@ -76,7 +76,7 @@ class Arith:
         return cls(conv_mode=CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)],
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
                    sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), affine_in_weights=_env_flag("GARMENTNETS_AFFINE_IN_WEIGHTS"),
-                   winograd=_env_flag("GARMENTNETS_WINOGRAD", False), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
+                   winograd=_env_flag("GARMENTNETS_WINOGRAD"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
                    fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
 
     def replace(self, **kw):

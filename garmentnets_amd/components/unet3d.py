@@ -29,22 +29,90 @@ def _wino_ok(arith, src0, cout):
             and (D // 4) * (H // 8) * (W // 8) * (cout // 128) * B >= 512)
 
 
+_ACT = {"r": ("ReLU", lambda: nn.ReLU(inplace=True), ops.ACT_RELU), "l": ("LeakyReLU", lambda: nn.LeakyReLU(negative_slope=0.1, inplace=True), ops.ACT_LEAKY),
+        "e": ("ELU", lambda: nn.ELU(inplace=True), ops.ACT_ELU)}
+
+
 class SingleConv(PackedModule, nn.Sequential):
-    """'gcr' block: GroupNorm(num_groups, Cin) -> Conv3d(Cin, Cout, 3, pad 1, no bias) -> ReLU."""
+    """One conv block of the reference's create_conv (components/unet3d.py:19-73), same module names and parameter layout for every layer order:
+    'g' GroupNorm, 'b' BatchNorm3d, 'c' Conv3d 3x3x3 pad 1 (bias only when the order has no norm layer), 'r' ReLU, 'l' LeakyReLU(0.1), 'e' ELU.
+    'gcr' -- what the GarmentNets pipeline ships -- runs on the fused split-operand kernels (run()); every other order ('cr', 'crg', 'cl', 'ce',
+    'bcr', ...) runs the convolution on the exact fp32-MFMA kernel with the pre-conv normalisation applied on load and the rest (bias, LeakyReLU / ELU,
+    a normalisation behind the non-linearity) through gn_affine_act: correct for any checkpoint, not tuned."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, order="gcr", num_groups=8, padding=1):
         super().__init__()
-        if order != "gcr" or kernel_size != 3 or padding != 1:
-            raise NotImplementedError("garmentnets_amd implements the 'gcr' 3x3x3 SingleConv used by the GarmentNets pipeline")
-        groups = num_groups if in_channels >= num_groups else 1
-        assert in_channels % groups == 0
-        self.add_module("groupnorm", nn.GroupNorm(num_groups=groups, num_channels=in_channels))
-        self.add_module("conv", nn.Conv3d(in_channels, out_channels, 3, padding=1, bias=False))
-        self.add_module("ReLU", nn.ReLU(inplace=True))
+        if kernel_size != 3 or padding != 1:
+            raise NotImplementedError("garmentnets_amd implements the 3x3x3, padding 1 SingleConv of the GarmentNets pipeline")
+        if "c" not in order or order.count("c") != 1:
+            raise ValueError("Conv layer MUST be present (exactly once)")
+        if order[0] in "rle":
+            raise ValueError("Non-linearity cannot be the first operation in the layer")
+        if any(ch not in "bgrlec" for ch in order):
+            raise ValueError(f"Unsupported layer type in {order!r}. MUST be one of ['b', 'g', 'r', 'l', 'e', 'c']")
+        if any(ch in "rle" for ch in order[:order.index("c")]) or sum(ch in "gb" for ch in order[:order.index("c")]) > 1:
+            raise NotImplementedError(f"layer order {order!r}: at most one normalisation and no non-linearity in front of the convolution")
+        self.order = order
+        for i, ch in enumerate(order):
+            before = i < order.index("c")
+            nch = in_channels if before else out_channels
+            if ch in _ACT:
+                self.add_module(_ACT[ch][0], _ACT[ch][1]())
+            elif ch == "c":
+                self.add_module("conv", nn.Conv3d(in_channels, out_channels, 3, padding=1, bias=not ("g" in order or "b" in order)))
+            elif ch == "g":
+                groups = num_groups if nch >= num_groups else 1
+                assert nch % groups == 0, f"Expected number of channels in input to be divisible by num_groups. num_channels={nch}, num_groups={groups}"
+                self.add_module("groupnorm", nn.GroupNorm(num_groups=groups, num_channels=nch))
+            elif ch == "b":
+                self.add_module("batchnorm", nn.BatchNorm3d(nch))
 
     def _pack(self):
         wp = ops.pack_conv_weight(self.conv.weight)                # [tap][Cin/16][Cout][16]
-        return wp, self.groupnorm.weight.detach().float().contiguous(), self.groupnorm.bias.detach().float().contiguous()
+        gn = getattr(self, "groupnorm", None)
+        return wp, (None if gn is None else gn.weight.detach().float().contiguous()), (None if gn is None else gn.bias.detach().float().contiguous())
+
+    def _norm_affine(self, ch, B, st0, st1):
+        """per-(sample, channel) affine of one normalisation layer from the statistics of what it normalises"""
+        if ch == "g":
+            return ops.groupnorm_affine(st0, st1, self.groupnorm.num_groups, self.groupnorm.eps, self.groupnorm.weight.detach().float().contiguous(),
+                                        self.groupnorm.bias.detach().float().contiguous())
+        bn = self.batchnorm                       # eval BatchNorm3d: running statistics
+        sc = (bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps))
+        sh = bn.bias.detach().double() - bn.running_mean.double() * sc
+        return sc.float().expand(B, -1).contiguous(), sh.float().expand(B, -1).contiguous()
+
+    def _run_generic(self, src0, src1, stats0, stats1, with_stats):
+        """every layer order but 'gcr' (see the class docstring)"""
+        order, ic = self.order, self.order.index("c")
+        B, cout = src0.shape[0], self.conv.out_channels
+        cin = src0.shape[-1] + (0 if src1 is None else src1.shape[-1])
+        wp, _, _ = self.packed()
+        if ic == 0:
+            a = torch.ones((B, cin), dtype=torch.float32, device=src0.device)
+            d = torch.zeros_like(a)
+        else:
+            st0 = st1 = None
+            if order[0] == "g":
+                st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
+                st1 = None if src1 is None else (stats1 if stats1 is not None else ops.channel_stats(src1))
+            a, d = self._norm_affine(order[0], B, st0, st1)
+        post = order[ic + 1:]
+        bias = None if self.conv.bias is None else self.conv.bias.detach().float().contiguous()
+        fuse_relu = bias is None and post[:1] == "r"
+        y = ops.conv3d_gcr(src0, src1, a, d, wp, cout, relu=fuse_relu)
+        k = 1 if fuse_relu else 0
+        if bias is not None:                      # conv bias, fused with the non-linearity that follows it (if one does)
+            act = _ACT[post[0]][2] if post[:1] and post[0] in _ACT else ops.ACT_NONE
+            ops.affine_act(y, bias=bias, act=act, out=y)
+            k = 1 if act != ops.ACT_NONE else 0
+        for ch in post[k:]:
+            if ch in _ACT:
+                ops.affine_act(y, act=_ACT[ch][2], out=y)
+            else:
+                na, nd = self._norm_affine(ch, B, ops.channel_stats(y) if ch == "g" else None, None)
+                ops.affine_act(y, a=na, d=nd, out=y)
+        return y, (ops.channel_stats(y) if with_stats else None)
 
     def run(self, src0, src1=None, stats0=None, stats1=None, with_stats=True, sparse=None, arith=None, rest0=None):
         """arith: the arith.Arith of this call (None: arith.DEFAULT).  src0 [B][D][H][W][C0] (full res), src1 [B][D/2][H/2][W/2][C1] or None -> ([B][D][H][W][Cout], output stats).
@@ -61,6 +129,8 @@ class SingleConv(PackedModule, nn.Sequential):
         rest0 [B][C0]: (polyphase form of a decoder layer) the value the skip connection src0 holds away from the cells: its full-resolution
         launch takes the affine-in-weights form as well."""
         arith = arith or AR.DEFAULT
+        if self.order != "gcr":
+            return self._run_generic(src0, src1, stats0, stats1, with_stats)
         wp, gamma, beta = self.packed()
         st0 = stats0 if stats0 is not None else ops.channel_stats(src0)
         st1 = None

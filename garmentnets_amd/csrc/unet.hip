@@ -453,3 +453,46 @@ extern "C" int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C
     GN_LAUNCH_CHECK("gn_maxpool3d_2");
     return GN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ elementwise: per-channel affine + bias + activation
+// The pieces of create_conv's layer orders other than 'gcr' (components/unet3d.py:19-73: 'cr', 'crg', 'cl', 'ce', 'bcr', ...) that the fused conv
+// kernels do not cover: a learnable conv bias (orders without a norm layer), LeakyReLU(0.1) / ELU, and a normalisation that FOLLOWS the
+// non-linearity ('crg': its GroupNorm affine is applied here).  y = act(x * a[b][c] + d[b][c] + bias[c]) over channel-last [B][V][C]; a, d, bias
+// may be NULL.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ELU(alpha = 1).  In place when out == x.  HBM-bound, a non-default path.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float *__restrict__ x, int64_t n4, int64_t VC4, int C4, const float *__restrict__ a,
+                                                         const float *__restrict__ d, const float *__restrict__ bias, int act, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t b = i / VC4;
+    const int c4 = (int)(i % C4);
+    float4 v = reinterpret_cast<const float4 *>(x)[i];
+    if (a) {
+        const float4 av = reinterpret_cast<const float4 *>(a)[b * C4 + c4], dv = reinterpret_cast<const float4 *>(d)[b * C4 + c4];
+        v.x = __fmaf_rn(v.x, av.x, dv.x); v.y = __fmaf_rn(v.y, av.y, dv.y); v.z = __fmaf_rn(v.z, av.z, dv.z); v.w = __fmaf_rn(v.w, av.w, dv.w);
+    }
+    if (bias) {
+        const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
+        v.x = __fadd_rn(v.x, bv.x); v.y = __fadd_rn(v.y, bv.y); v.z = __fadd_rn(v.z, bv.z); v.w = __fadd_rn(v.w, bv.w);
+    }
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float t = r[k];
+        if (act == 1) r[k] = gn_relu(t);
+        else if (act == 2) r[k] = t > 0.f ? t : __fmul_rn(t, 0.1f);
+        else if (act == 3) r[k] = t > 0.f ? t : expm1f(t);
+    }
+    reinterpret_cast<float4 *>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+extern "C" int gn_affine_act(const float *x, int B, int64_t V, int C, const float *a, const float *d, const float *bias, int act, float *out, void *stream) {
+    GN_REQUIRE(B >= 0 && V >= 0 && C > 0 && C % 4 == 0, "gn_affine_act: C must be a multiple of 4");
+    GN_REQUIRE(act >= 0 && act <= 3, "gn_affine_act: act must be 0 (none), 1 (ReLU), 2 (LeakyReLU 0.1) or 3 (ELU)");
+    GN_REQUIRE((a == nullptr) == (d == nullptr), "gn_affine_act: a and d come together");
+    if (B == 0 || V == 0) return GN_OK;
+    GN_REQUIRE(x && out, "gn_affine_act: null pointer");
+    const int64_t n4 = (int64_t)B * V * (C / 4);
+    hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)gn_cdiv(n4, 256)), dim3(256), 0, gn_stream(stream), x, n4, V * (C / 4), C / 4, a, d, bias, act, out);
+    GN_LAUNCH_CHECK("gn_affine_act");
+    return GN_OK;
+}

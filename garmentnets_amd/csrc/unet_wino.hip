@@ -67,7 +67,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
     const int n0 = cb * 128 + cg * 64;
     const int nslices = Cin / SP_KS;
 
-    f32x16s acc[NT], tot[2][NT];                    // tot[e]: outputs at even (e = 0) / odd x of the pairs
+    // acc: the running transform position's accumulators; tot[e]: outputs at even (e = 0) / odd x of the pairs.  (A second accumulator set -- the
+    // output transform of position j folded in under position j+1's MFMAs -- needs 261 registers: 46 spilled values inside the MFMA stream.)
+    f32x16s acc[NT], tot[2][NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -76,20 +78,27 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
     {
     for (int i = tid; i < Cin; i += 512) { adl[i] = p.a[(int64_t)b * Cin + i]; adl[ADN + i] = p.d[(int64_t)b * Cin + i]; }
 
-    // B fragments: pack order [slice][step = (j * 3 + dz) * 3 + dy][Cout/32][plane][lane]; wave w fetches piece w of each of a group's three steps
+    // B fragments: pack order [slice][step = (j * 3 + dz) * 3 + dy][Cout/32][plane][lane]; wave w fetches piece w of every step (wave-uniform
+    // base in SGPRs + one constant per-lane offset register: no 64-bit VALU arithmetic per piece).  Step (G + 2, st) is issued during step
+    // (G, st) -- BETWEEN that step's MFMAs, so that the ~60-100 cycles a piece costs to issue are spent in the matrix pipe's shadow and not,
+    // by both waves of a SIMD at once, right behind the hand-over barrier
     const int64_t bstep = (int64_t)(p.Cout / 32) * P * 1024;
-    const unsigned char *bg = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)b * p.wp_bstride + (int64_t)cb * STEPB + wave * 1024 + lane * 16;
-#define WN_ISSUE_B(SLOTI)                                                                                                      \
+    const unsigned char *bgs = reinterpret_cast<const unsigned char *>(p.wp) + (int64_t)b * p.wp_bstride + (int64_t)cb * STEPB;   // (uniform)
+    const unsigned bvoff = (unsigned)(wave * 1024 + lane * 16);
+#define WN_ISSUE_PIECE(SLOTI, ST)                                                                                              \
     do {                                                                                                                       \
-        _Pragma("unroll") for (int st = 0; st < 3; ++st)                                                                       \
-            gn_glds16(bg + st * bstep, lds_ring + (SLOTI) * GB + st * STEPB + wave * 1024);                                    \
-        bg += 3 * bstep;                                                                                                       \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bvoff), "s"(bgs),                    \
+                     "s"(lds_ring + (SLOTI) * GB + (ST) * STEPB + wave * 1024) : "memory");                                    \
+        bgs += bstep;                                                                                                          \
     } while (0)
-    WN_ISSUE_B(0);
-    WN_ISSUE_B(1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) WN_ISSUE_PIECE(i / 3, i % 3);             // groups 0 and 1
 
     // ---- staging.  thread = (halo row hz * 10 + hy, x half xh, channel quad): voxels x0 + 4 xh - 1 .. + 4 of that row -> pairs 2 xh, 2 xh + 1
-    const int srow = tid >> 3, xh = (tid >> 2) & 1, c4 = (tid & 3) * 4;
+    // lane bits: [1:0] channel quad, [3:2] row + 0 / 2 / 4 / 6, [4] row + 1, [5] x half -- the 16 lanes of a ds_write_b64 service group then cover
+    // the 32 store banks once (row pitch 272 B = 4 banks mod 32: rows R, R+2, R+4, R+6 sit 8 banks apart; the two x halves of a row are
+    // exactly 32 banks apart and would collide: they are in different groups).  The (tid >> 3, (tid >> 2) & 1) order was 4-way conflicted
+    const int srow = (tid >> 6) * 8 + 2 * ((tid >> 2) & 3) + ((tid >> 4) & 1), xh = (tid >> 5) & 1, c4 = (tid & 3) * 4;
     // (threads 480 .. 511 have no row of their own: they repeat row 59's work -- the same values to the same addresses -- instead of
     //  branching around it: a divergent branch inside the unrolled MFMA stream cuts it into basic blocks)
     const int rr = srow < WL::HZ * WL::HY ? srow : WL::HZ * WL::HY - 1;
@@ -176,12 +185,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
             _Pragma("unroll") for (int i = 0; i < P; ++i)                                                                      \
                 fb[SET][u][i] = *reinterpret_cast<const uint4 *>(ring_rd + (RING_OFF) + (u * P + i) * 1024);                    \
     } while (0)
-    // smallest terms first, the two accumulators alternating
-#define WN_PROD(SET)                                                                                                           \
+    // smallest terms first, the two accumulators alternating; WN_PROD_A: the first product pair, WN_PROD_B: the other two
+#define WN_PROD_A(SET, AC)                                                                                                     \
+    do { AC[0] = mfma16<F16>(fa[SET][1], fb[SET][0][0], AC[0]); AC[1] = mfma16<F16>(fa[SET][1], fb[SET][1][0], AC[1]); } while (0)
+#define WN_PROD_B(SET, AC)                                                                                                     \
     do {                                                                                                                       \
-        acc[0] = mfma16<F16>(fa[SET][1], fb[SET][0][0], acc[0]); acc[1] = mfma16<F16>(fa[SET][1], fb[SET][1][0], acc[1]);       \
-        acc[0] = mfma16<F16>(fa[SET][0], fb[SET][0][1], acc[0]); acc[1] = mfma16<F16>(fa[SET][0], fb[SET][1][1], acc[1]);       \
-        acc[0] = mfma16<F16>(fa[SET][0], fb[SET][0][0], acc[0]); acc[1] = mfma16<F16>(fa[SET][0], fb[SET][1][0], acc[1]);       \
+        AC[0] = mfma16<F16>(fa[SET][0], fb[SET][0][1], AC[0]); AC[1] = mfma16<F16>(fa[SET][0], fb[SET][1][1], AC[1]);           \
+        AC[0] = mfma16<F16>(fa[SET][0], fb[SET][0][0], AC[0]); AC[1] = mfma16<F16>(fa[SET][0], fb[SET][1][0], AC[1]);           \
+    } while (0)
+    // output transform of transform position J: out[x] = m0 + m1 + m2, out[x+1] = m1 - m2 - m3
+#define WN_FLUSH(J, AC)                                                                                                        \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < NT; ++u)                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                   \
+                const float m = AC[u][q];                                                                                      \
+                if ((J) <= 2) tot[0][u][q] = __fadd_rn(tot[0][u][q], m);                                                       \
+                if ((J) == 1) tot[1][u][q] = __fadd_rn(tot[1][u][q], m);                                                       \
+                if ((J) >= 2) tot[1][u][q] = __fsub_rn(tot[1][u][q], m);                                                       \
+            }                                                                                                                  \
     } while (0)
     WN_READ(0, 0, 0, 0);
 
@@ -199,51 +220,56 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
 #pragma unroll
         for (int g = 0; g < 12; ++g) {
             const int j = g / 3, dz = g % 3, X = g & 1, Y = X ^ 1;
-            // hand-over of group g.  VM queue, oldest first: the three DMAs of group g+1 (issued one group ago) and, at g == 1 only, the NIT
-            // row loads issued right behind them: they may still be in flight there.  Groups 3, 5, 8, 11 follow a conversion group: their
-            // barrier also publishes this wave's halo stores (lgkmcnt(0); elsewhere the only LDS operations in flight are the fragment reads
-            // issued a few instructions ago, which hipcc waits for right before the MFMA that consumes them)
-            if (g == 1) GN_WAIT_VM_ONLY(NIT);
-            else if (g == 3 || g == 5 || g == 8 || g == 11) GN_WAIT_VM_LGKM0(0);
-            else GN_WAIT_VM_ONLY(0);
+            // hand-over of group g.  Must have landed: steps 1, 2 of this group (issued two groups ago) and step 0 of the next one (issued
+            // during the previous group's step 0; it is read at the end of this group).  VM queue, oldest first: ..., (g+1, 0), (g+1, 1),
+            // (g+1, 2): the youngest two may stay in flight; at g == 1 also the NIT row loads issued at the very end of group 0.  Groups 3, 5, 8,
+            // 11 follow a conversion group: their barrier also publishes this wave's halo stores (lgkmcnt(0); elsewhere the only LDS operations
+            // in flight are the fragment reads issued a few instructions ago, which hipcc waits for right before the MFMA that consumes them)
+            if (g == 1) GN_WAIT_VM_ONLY(2 + NIT);
+            else if (g == 3 || g == 5 || g == 8 || g == 11) GN_WAIT_VM_LGKM0(2);
+            else GN_WAIT_VM_ONLY(2);
             __builtin_amdgcn_s_barrier();
-            WN_ISSUE_B((g + 2) % RING);             // group g+2 -> the slot group g-1 vacated
-            if (g == 0) issue_rows(sn);             // always (uniform wait counts); unused after the last slice
             WN_READ(Y, slo[j], dz * WL::HY + 1, (g % RING) * GB + STEPB);
             __builtin_amdgcn_sched_barrier(0);
-            WN_PROD(X);
-            // (also behind the last slice, into slots nobody reads any more: no branch inside the MFMA stream)
+            WN_PROD_A(X, acc);
+            WN_ISSUE_PIECE((g + 2) % RING, 0);      // group g+2 -> the slot group g-1 vacated
+            WN_PROD_B(X, acc);
+            // (conversions also behind the last slice, into slots nobody reads any more: no branch inside the MFMA stream)
             if (g == 2) { affine_rows(sn); convert(0, nslo[0]); }
             if (g == 4) convert(1, nslo[1]);
             if (g == 7) convert(2, nslo[2]);
             if (g == 10) convert(3, nslo[3]);
             WN_READ(X, slo[j], dz * WL::HY + 2, (g % RING) * GB + 2 * STEPB);
-            WN_PROD(Y);
+            __builtin_amdgcn_sched_barrier(0);
+            WN_PROD_A(Y, acc);
+            WN_ISSUE_PIECE((g + 2) % RING, 1);
+            WN_PROD_B(Y, acc);
             {   // first step of the next group
                 const int g1 = g + 1 < 12 ? g + 1 : 0;
                 const int so = g + 1 < 12 ? slo[g1 / 3] : nslo[0] * WL::SLOT;
                 WN_READ(Y, so, (g1 % 3) * WL::HY, ((g + 1) % RING) * GB);
             }
-            WN_PROD(X);
             __builtin_amdgcn_sched_barrier(0);
-            if (dz == 2) {                          // output transform of transform position j: out[x] = m0 + m1 + m2, out[x+1] = m1 - m2 - m3
+            WN_PROD_A(X, acc);
+            WN_ISSUE_PIECE((g + 2) % RING, 2);
+            WN_PROD_B(X, acc);
+            if (g == 0) issue_rows(sn);             // always (uniform wait counts); unused after the last slice
+            __builtin_amdgcn_sched_barrier(0);
+            if (dz == 2) {                          // this transform position is complete: fold it into the totals, restart the accumulators
+                WN_FLUSH(j, acc);
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float m = acc[u][q];
-                        if (j <= 2) tot[0][u][q] = __fadd_rn(tot[0][u][q], m);
-                        if (j == 1) tot[1][u][q] = __fadd_rn(tot[1][u][q], m);
-                        if (j >= 2) tot[1][u][q] = __fsub_rn(tot[1][u][q], m);
-                        acc[u][q] = 0.f;
-                    }
+                    for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
             }
         }
         sbase = nbase;
     }
-#undef WN_ISSUE_B
+#undef WN_ISSUE_PIECE
+#undef WN_FLUSH
+#undef WN_PROD_A
+#undef WN_PROD_B
 #undef WN_READ
-#undef WN_PROD
     GN_WAIT_VM_LGKM0(0);
     }
     __syncthreads();                                // look-ahead DMAs landed; the epilogue reuses the LDS as scratch

@@ -65,11 +65,15 @@ class _Codec:
                                           f"are handled without it)")
             self.impl = nc.get_codec(config)
 
-    def encode(self, raw):
+    def encode(self, block):
+        """block: a C-contiguous ndarray chunk.  numcodecs codecs get the TYPED array (as zarr hands it over: Blosc takes its typesize -- what
+        BITSHUFFLE shuffles over -- from the array's itemsize; a bytes object would be typesize 1: readable, but neither byte-comparable with the
+        reference's chunks nor as well compressed)"""
+        if self.impl is not None:
+            return bytes(self.impl.encode(block))
+        raw = block.tobytes()
         if self.config is None:
             return raw
-        if self.impl is not None:
-            return bytes(self.impl.encode(raw))
         return zlib.compress(raw, self.config.get("level", 1))
 
     def decode(self, raw):
@@ -132,7 +136,7 @@ class Group:
                 block[tuple(slice(0, s.stop - s.start) for s in sl)] = data[sl]
             else:
                 block = data
-            raw = codec.encode(np.ascontiguousarray(block).tobytes())
+            raw = codec.encode(np.ascontiguousarray(block))
             with open(os.path.join(apath, ".".join(str(i) for i in ci) if ci else "0"), "wb") as f:
                 f.write(raw)
 

@@ -544,6 +544,20 @@ def conv3d_gcr(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
     return (out, (s, q, D * H * W)) if with_stats else out
 
 
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU = 0, 1, 2, 3
+
+
+def affine_act(x, a=None, d=None, bias=None, act=ACT_NONE, out=None):
+    """y = act(x * a[b][c] + d[b][c] + bias[c]) over a channel-last volume [B][...][C] (gn_affine_act: the non-'gcr' layer orders' odds and ends);
+    in place when out is x"""
+    B, C = x.shape[0], x.shape[-1]
+    V = x.numel() // max(B * C, 1)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("gn_affine_act", _p(x), B, V, C, _p(a), _p(d), _p(bias), int(act), _p(out), _stream())
+    return out
+
+
 def maxpool3d_2(x, with_stats=False):
     B, D, H, W, C = x.shape
     out = torch.empty((B, D // 2, H // 2, W // 2, C), dtype=torch.float32, device=x.device)

@@ -272,6 +272,12 @@ int gn_conv3d_gcr_split_wino(const float *src, int Cin, const float *a, const fl
 int gn_upconv_partial(const float *src1, int C1, const float *a, const float *d, const void *wp, int mode, const float *out_scale,
                       const float *act_inv_scale, int B, int Dc, int Hc, int Wc, int Cout, float *partial, void *stream);
 
+/* The pieces of create_conv's layer orders other than 'gcr' (components/unet3d.py:19-73: 'cr', 'crg', 'cl', 'ce', 'bcr', ...) that the fused conv
+ * kernels do not cover -- a learnable conv bias, LeakyReLU(0.1) / ELU, a normalisation BEHIND the non-linearity:
+ * y = act(x * a[b][c] + d[b][c] + bias[c]) over channel-last [B][V][C] (C % 4 == 0); a / d ([B][C], together) and bias ([C]) may be NULL;
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 ELU(alpha 1).  In place when out == x. */
+int gn_affine_act(const float *x, int B, int64_t V, int C, const float *a, const float *d, const float *bias, int act, float *out, void *stream);
+
 /* MaxPool3d(2) -- components/unet3d.py:222.  in [B][D][H][W][C] -> out [B][D/2][H/2][W/2][C].
  * out_sum / out_sumsq: optional statistics of the pooled output (as gn_conv3d_gcr). */
 int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *out, double *out_sum, double *out_sumsq,

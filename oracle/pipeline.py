@@ -207,17 +207,35 @@ def unet_channel_plan(in_channels, f_maps, num_levels):
     return plan, f_maps
 
 
-def _single_conv(sd, p, x, num_groups):
-    c = x.shape[1]
-    g = num_groups if c >= num_groups else 1
-    x = F.group_norm(x, g, sd[p + ".groupnorm.weight"], sd[p + ".groupnorm.bias"], eps=1e-5)
-    x = F.conv3d(x, sd[p + ".conv.weight"], None, padding=1)
-    return F.relu(x)
+def _single_conv(sd, p, x, num_groups, order="gcr"):
+    """components/unet3d.py:19-73 (create_conv) walked character by character: 'g' GroupNorm (over the channels it sees: the input's before the
+    convolution, the output's behind it; one group when there are fewer channels than groups), 'b' BatchNorm3d (eval), 'c' Conv3d 3x3x3 pad 1
+    (with a bias only when the order has no norm layer), 'r' ReLU, 'l' LeakyReLU(0.1), 'e' ELU."""
+    assert "c" in order and order[0] not in "rle"
+    for ch in order:
+        if ch == "g":
+            c = x.shape[1]
+            g = num_groups if c >= num_groups else 1
+            x = F.group_norm(x, g, sd[p + ".groupnorm.weight"], sd[p + ".groupnorm.bias"], eps=1e-5)
+        elif ch == "b":
+            x = F.batch_norm(x, sd[p + ".batchnorm.running_mean"], sd[p + ".batchnorm.running_var"], sd[p + ".batchnorm.weight"],
+                             sd[p + ".batchnorm.bias"], training=False, eps=1e-5)
+        elif ch == "c":
+            x = F.conv3d(x, sd[p + ".conv.weight"], sd.get(p + ".conv.bias"), padding=1)
+        elif ch == "r":
+            x = F.relu(x)
+        elif ch == "l":
+            x = F.leaky_relu(x, 0.1)
+        elif ch == "e":
+            x = F.elu(x)
+        else:
+            raise ValueError(f"unsupported layer type {ch!r}")
+    return x
 
 
 def unet3d(sd, hp, x, prefix="unet_3d.abstract_3d_unet", return_intermediates=False):
-    """components/unet3d.py:449-474 with DoubleConv 'gcr'."""
-    assert hp.get("layer_order", "gcr") == "gcr"
+    """components/unet3d.py:449-474 with DoubleConv in any create_conv layer order (the shipped one: 'gcr')."""
+    order = hp.get("layer_order", "gcr")
     ng = hp.get("num_groups", 8)
     nl = hp.get("num_levels", 4)
     f_maps = hp["f_maps"]
@@ -228,7 +246,7 @@ def unet3d(sd, hp, x, prefix="unet_3d.abstract_3d_unet", return_intermediates=Fa
         if i > 0:
             x = F.max_pool3d(x, 2)
         for j in (1, 2):
-            x = _single_conv(sd, f"{prefix}.encoders.{i}.basic_module.SingleConv{j}", x, ng)
+            x = _single_conv(sd, f"{prefix}.encoders.{i}.basic_module.SingleConv{j}", x, ng, order)
         inter[f"enc{i}"] = x
         skips.insert(0, x)
     skips = skips[1:]
@@ -236,7 +254,7 @@ def unet3d(sd, hp, x, prefix="unet_3d.abstract_3d_unet", return_intermediates=Fa
         x = F.interpolate(x, size=s.shape[2:], mode="nearest")
         x = torch.cat((s, x), dim=1)
         for j in (1, 2):
-            x = _single_conv(sd, f"{prefix}.decoders.{i}.basic_module.SingleConv{j}", x, ng)
+            x = _single_conv(sd, f"{prefix}.decoders.{i}.basic_module.SingleConv{j}", x, ng, order)
         inter[f"dec{i}"] = x
     x = F.conv3d(x, sd[prefix + ".final_conv.weight"], sd[prefix + ".final_conv.bias"])
     if return_intermediates:

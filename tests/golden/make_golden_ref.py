@@ -254,10 +254,60 @@ def grid_case():
     print("gridding ->", path)
 
 
+CONV_ORDERS = ("gcr", "cr", "crg", "cl", "ce", "bcr", "cbr", "cgr")
+
+
+def conv_orders_case():
+    """Reference SingleConv (components/unet3d.py:19-91, create_conv) for every layer order the docstrings name, on ONE shared set of parameters, and a
+    small Abstract3DUNet with layer_order='crg' (the reference SingleConv's own default) end to end -> ref_conv_orders.npz (data only)."""
+    from components.unet3d import Abstract3DUNet, DoubleConv, SingleConv
+    g = torch.Generator().manual_seed(77)
+    cin, cout, ng = 16, 32, 4
+    rn = lambda *shape: torch.randn(*shape, generator=g)
+    out = {"x": rn(2, cin, 4, 6, 8), "w": rn(cout, cin, 3, 3, 3) / (27 * cin) ** 0.5, "conv_bias": rn(cout) * 0.1}
+    for tag, c in (("in", cin), ("out", cout)):
+        out[f"gn_{tag}_weight"], out[f"gn_{tag}_bias"] = torch.rand(c, generator=g) + 0.5, rn(c) * 0.2
+        out[f"bn_{tag}_weight"], out[f"bn_{tag}_bias"] = torch.rand(c, generator=g) + 0.5, rn(c) * 0.2
+        out[f"bn_{tag}_mean"], out[f"bn_{tag}_var"] = rn(c) * 0.3, torch.rand(c, generator=g) + 0.5
+    for order in CONV_ORDERS:
+        m = SingleConv(cin, cout, kernel_size=3, order=order, num_groups=ng).eval()
+        tag = "in" if any(ch in order[:order.index("c")] for ch in "gb") else "out"
+        sd = {"conv.weight": out["w"]}
+        if m.conv.bias is not None:
+            sd["conv.bias"] = out["conv_bias"]
+        if "g" in order:
+            sd["groupnorm.weight"], sd["groupnorm.bias"] = out[f"gn_{tag}_weight"], out[f"gn_{tag}_bias"]
+        if "b" in order:
+            sd.update({"batchnorm.weight": out[f"bn_{tag}_weight"], "batchnorm.bias": out[f"bn_{tag}_bias"], "batchnorm.running_mean": out[f"bn_{tag}_mean"],
+                       "batchnorm.running_var": out[f"bn_{tag}_var"], "batchnorm.num_batches_tracked": torch.tensor(0)})
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            out["y_" + order] = m(out["x"].clone())
+    torch.manual_seed(78)
+    net = Abstract3DUNet(in_channels=16, out_channels=16, final_sigmoid=False, basic_module=DoubleConv, f_maps=8, layer_order="crg", num_groups=4,
+                         num_levels=2, is_segmentation=False).eval()
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.2 if prm.dim() > 1 else 0.3))
+    xu = rn(2, 16, 8, 8, 8)
+    with torch.no_grad():
+        yu = net(xu)
+    for k, v in net.state_dict().items():
+        out["unet_crg." + k] = v
+    out["unet_crg_x"], out["unet_crg_y"] = xu, yu
+    path = os.path.join(REPO, "tests", "golden", "ref_conv_orders.npz")
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
+    print("conv orders ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted: goldens can only be generated in the build container"
     torch.set_num_threads(8)
     install_stubs()
+    if sys.argv[1:] == ["conv_orders"]:
+        conv_orders_case()
+        sys.exit(0)
+    conv_orders_case()
     grid_case()
     unet_case("unet_g8", 8, 2, 5)
     unet_case("unet_g16", 16, 1, 6)

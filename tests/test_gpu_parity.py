@@ -595,6 +595,57 @@ def test_unet_against_reference_module(golden_dir, name):
     assert np.abs(y - y64).max() <= 2 * max(np.abs(g["y"] - y64).max(), 2.5e-5)   # as accurate as the reference's own fp32 path
 
 
+CONV_ORDERS = ("gcr", "cr", "crg", "cl", "ce", "bcr", "cbr", "cgr")
+
+
+@pytest.mark.parametrize("order", CONV_ORDERS)
+def test_conv_layer_orders_against_reference_golden(golden_dir, order):
+    """every create_conv layer order (components/unet3d.py:19-91), not only the shipped 'gcr': the HIP SingleConv on the reference module's golden
+    input / parameters / output (tests/golden/make_golden_ref.py conv_orders_case).  'gcr' takes the fused f16x2 path, the others the fp32-MFMA
+    convolution + gn_affine_act"""
+    from test_oracle_golden import conv_order_state
+    from garmentnets_amd.components.unet3d import SingleConv
+    z = np.load(os.path.join(golden_dir, "ref_conv_orders.npz"))
+    m = SingleConv(16, 32, order=order, num_groups=4)
+    sd = conv_order_state(z, order)
+    if "b" in order:
+        sd["batchnorm.num_batches_tracked"] = torch.tensor(0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(z["x"]).permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    with torch.no_grad():
+        y, st = m.run(x, with_stats=True)
+    got = y.permute(0, 4, 1, 2, 3).cpu().numpy()
+    ref = z["y_" + order]
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(st[0].cpu().numpy(), got.astype(np.float64).sum(axis=(2, 3, 4)), rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("order", ["crg", "bcr", "cl"])
+def test_unet_other_layer_orders_against_oracle(order):
+    """a whole Abstract3DUNet (encoder, max-pool, two-source decoder convs, final conv) in a non-default layer order against the oracle's
+    restatement, which tests/test_oracle_golden.py pins to the reference's modules for these orders"""
+    from garmentnets_amd.components.unet3d import Abstract3DUNet
+    torch.manual_seed(5)
+    net = Abstract3DUNet(in_channels=32, out_channels=16, f_maps=32, layer_order=order, num_groups=8, num_levels=2)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for name, prm in net.named_parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.05 if prm.dim() > 1 else 0.3) + (1.0 if name.endswith("norm.weight") else 0.0))
+        for name, buf in net.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.2)
+    net = net.eval()
+    sd = {"u." + k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(2, 32, 8, 8, 8, generator=g)
+    with torch.no_grad():
+        ref = P.unet3d(sd, dict(f_maps=32, layer_order=order, num_groups=8, num_levels=2), x, prefix="u").numpy()
+        y = net.to(DEV)(x.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+
+
 def test_trilinear_against_grid_sample():
     g = torch.Generator().manual_seed(2)
     vol = torch.randn(1, 24, 5, 7, 9, generator=g)

@@ -325,6 +325,7 @@ def _fake_numcodecs():
     import types, zlib
     mod = types.ModuleType("numcodecs")
     mod.calls = []
+    mod.itemsizes = []               # what Blosc would take as its typesize (the shuffle width): the itemsize of the buffer it is handed
 
     class Codec:
         def __init__(self, config):
@@ -332,6 +333,7 @@ def _fake_numcodecs():
 
         def encode(self, buf):
             mod.calls.append(("encode", self.config["id"]))
+            mod.itemsizes.append(np.asarray(buf).dtype.itemsize if hasattr(buf, "dtype") else 1)
             return b"FAKE" + self.config["id"].encode() + b":" + zlib.compress(bytes(buf), 1)
 
         def decode(self, buf):
@@ -367,6 +369,7 @@ def test_zarr_store_numcodecs_guard(tmp_path, monkeypatch):
     assert meta["compressor"] == {"id": "blosc", "cname": "zstd", "clevel": 6, "shuffle": 2, "blocksize": 0}
     assert open(os.path.join(g.path, "marching_cubes_mesh", "verts", "0.0"), "rb").read().startswith(b"FAKEblosc:")
     assert np.array_equal(g["marching_cubes_mesh"]["verts"], data) and ("decode", "blosc") in fake.calls
+    assert fake.itemsizes and all(sz == 4 for sz in fake.itemsizes)          # typed float32 chunks reach the codec (Blosc typesize 4, as zarr passes them)
     # a chunked input array under another registry codec, as a foreign writer would leave it
     root2.require_group("in").array("pts", data, chunks=(16, 2), compressor={"id": "lz4", "acceleration": 1})
     assert np.array_equal(root2["in"]["pts"], data) and ("decode", "lz4") in fake.calls

@@ -137,6 +137,45 @@ def test_unet_against_reference_module(golden_dir, name):
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
 
 
+CONV_ORDERS = ("gcr", "cr", "crg", "cl", "ce", "bcr", "cbr", "cgr")
+
+
+def conv_order_state(z, order):
+    """state dict of a SingleConv of layer order `order` from the shared parameter set of ref_conv_orders.npz (as make_golden_ref.conv_orders_case
+    loaded it into the reference's module)"""
+    t = lambda k: torch.from_numpy(z[k])
+    tag = "in" if any(ch in order[:order.index("c")] for ch in "gb") else "out"
+    sd = {"conv.weight": t("w")}
+    if not ("g" in order or "b" in order):
+        sd["conv.bias"] = t("conv_bias")
+    if "g" in order:
+        sd["groupnorm.weight"], sd["groupnorm.bias"] = t(f"gn_{tag}_weight"), t(f"gn_{tag}_bias")
+    if "b" in order:
+        sd.update({"batchnorm.weight": t(f"bn_{tag}_weight"), "batchnorm.bias": t(f"bn_{tag}_bias"), "batchnorm.running_mean": t(f"bn_{tag}_mean"),
+                   "batchnorm.running_var": t(f"bn_{tag}_var")})
+    return sd
+
+
+@pytest.mark.parametrize("order", CONV_ORDERS)
+def test_conv_layer_orders_against_reference_module(golden_dir, order):
+    """oracle _single_conv for every create_conv layer order == the reference's SingleConv (components/unet3d.py:19-91) on the golden parameters"""
+    z = np.load(os.path.join(golden_dir, "ref_conv_orders.npz"))
+    sd = {"m." + k: v for k, v in conv_order_state(z, order).items()}
+    with torch.no_grad():
+        y = P._single_conv(sd, "m", torch.from_numpy(z["x"]), 4, order)
+    assert float((y - torch.from_numpy(z["y_" + order])).abs().max()) == 0.0
+
+
+def test_unet_layer_order_crg_against_reference_module(golden_dir):
+    """the whole UNet with layer_order='crg' (the reference SingleConv's own default; the pipeline ships 'gcr')"""
+    z = np.load(os.path.join(golden_dir, "ref_conv_orders.npz"))
+    sd = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("unet_crg.")}
+    hp = dict(in_channels=16, out_channels=16, f_maps=8, layer_order="crg", num_groups=4, num_levels=2)
+    with torch.no_grad():
+        y = P.unet3d(sd, hp, torch.from_numpy(z["unet_crg_x"]), prefix="unet_crg")
+    assert float((y - torch.from_numpy(z["unet_crg_y"])).abs().max()) == 0.0
+
+
 def test_gridding_luts(golden_dir):
     g = _load(golden_dir, "ref_gridding.npz")
     bins = torch.arange(64).unsqueeze(1).repeat(1, 3)

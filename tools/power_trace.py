@@ -147,6 +147,58 @@ class HwmonSampler:
                           "amdgpu hwmon nodes of this GPU are not readable from the process"}
 
 
+_THROTTLE_CHILD = r"""
+import json, sys
+sys.path.insert(0, "/opt/rocm/share/amd_smi")
+import amdsmi
+amdsmi.amdsmi_init()
+want = sys.argv[1].lower()
+out = None
+for h in amdsmi.amdsmi_get_processor_handles():
+    try:
+        bdf = amdsmi.amdsmi_get_gpu_device_bdf(h).lower()
+    except Exception:
+        continue
+    if want and not bdf.startswith(want):
+        continue
+    v = amdsmi.amdsmi_get_violation_status(h)
+    keep = ("acc_counter", "acc_prochot_thrm", "acc_ppt_pwr", "acc_socket_thrm", "acc_vr_thrm", "acc_hbm_thrm", "acc_gfx_clk_below_host_limit",
+            "active_prochot_thrm", "active_ppt_pwr", "active_socket_thrm", "active_vr_thrm", "active_hbm_thrm")
+    out = {k: (v[k] if isinstance(v.get(k), (int, float, bool)) else None) for k in keep}
+    out["bdf"] = bdf
+    break
+print(json.dumps(out))
+"""
+
+
+def throttle_read(device_index=0):
+    """the firmware's throttle-residency accumulators of ONE GPU (amdsmi violation status = the gpu_metrics accumulation counters: PPT / power,
+    socket thermal, VR thermal, HBM thermal, PROCHOT), read in a child process so that the SMI library never shares an address space with HIP.
+    -> dict or None.  Two reads around a pass give the share of the pass the firmware spent limiting the clock for each reason."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        r = subprocess.run([sys.executable, "-c", _THROTTLE_CHILD, bdf], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def throttle_window(before, after):
+    """residency of each limiter between two throttle_read() samples: accumulator delta / accumulation-counter delta"""
+    if not before or not after or before.get("acc_counter") is None or after.get("acc_counter") is None:
+        return {"available": False, "why_not": "amdsmi violation status (gpu_metrics throttle accumulators) not readable from this process"}
+    dt = after["acc_counter"] - before["acc_counter"]
+    out = {"available": True, "accumulation_ticks": dt, "source": "amdsmi_get_violation_status (amdgpu gpu_metrics throttler residency accumulators), read before / after the pass"}
+    for k, name in (("acc_ppt_pwr", "ppt_power_limit"), ("acc_socket_thrm", "socket_thermal"), ("acc_vr_thrm", "vr_thermal"), ("acc_hbm_thrm", "hbm_thermal"),
+                    ("acc_prochot_thrm", "prochot"), ("acc_gfx_clk_below_host_limit", "gfx_clk_below_host_limit")):
+        a, b = before.get(k), after.get(k)
+        out[name + "_residency"] = ((b - a) / dt) if (a is not None and b is not None and dt > 0) else None
+    out["active_at_end"] = [k[7:] for k in ("active_ppt_pwr", "active_socket_thrm", "active_vr_thrm", "active_hbm_thrm", "active_prochot_thrm") if after.get(k)]
+    return out
+
+
 def main():
     out, cmd = sys.argv[1], sys.argv[2:]
     mine = hip_card()
