@@ -23,14 +23,30 @@ def number_of_features_per_level(init_channel_number, num_levels):
 
 
 def _wino_ok(arith, src0, cout):
-    """the launch would take the 128-wide kernel and fits its Winograd form (arith.winograd; csrc/unet_wino.hip)"""
-    B, D, H, W, cin = src0.shape
+    """the layer fits the Winograd form of the 128-wide kernel (arith.winograd; csrc/unet_wino.hip).  Decided from the SAMPLE's shape alone, never
+    from the batch size: the Winograd and the direct form round differently, and a garment's result must not depend on how many garments share its
+    batch (the direct kernels may switch variant with the batch size because they are bit-identical to each other)"""
+    _, D, H, W, cin = src0.shape
     return (arith.winograd and arith.conv_mode == ops.SPLIT_F16X2 and ops.wino_supported(cin, cout, (D, H, W))
-            and (D // 4) * (H // 8) * (W // 8) * (cout // 128) * B >= 512)
+            and (D // 4) * (H // 8) * (W // 8) * (cout // 128) >= 32)
 
 
 _ACT = {"r": ("ReLU", lambda: nn.ReLU(inplace=True), ops.ACT_RELU), "l": ("LeakyReLU", lambda: nn.LeakyReLU(negative_slope=0.1, inplace=True), ops.ACT_LEAKY),
         "e": ("ELU", lambda: nn.ELU(inplace=True), ops.ACT_ELU)}
+
+
+def _class_constants(small_out, reach, cout):
+    """border-class constants of an occupancy-aware launch from the layer's output over a small all-at-rest volume (n^3, n = 5 for the direct
+    kernels, 8 -- the smallest volume of whole tiles -- for the Winograd kernel): per axis the voxels at distance 0 [, 1] from either face and one
+    in the middle.  (Winograd along x: voxel 0 / n-1 of the small volume has the parity of voxel 0 / W-1 of the real one, n and W being multiples
+    of 8, and away from the cells both members of an output pair hold the same value -- the differences d0 - d2, d2 - d1, d1 - d3 are exactly zero.)
+    Strided / indexed views of a device tensor: nothing comes from the host, the path can be captured into a HIP graph."""
+    B, n = small_out.shape[0], small_out.shape[1]
+    pos = [0, n // 2, n - 1] if reach == 1 else [0, 1, n // 2, n - 2, n - 1]
+    k = small_out
+    for dim in (1, 2, 3):                          # (narrow + cat: device-side copies only -- an index tensor would be a host-to-device copy)
+        k = torch.cat([k.narrow(dim, q, 1) for q in pos], dim=dim)
+    return k.reshape(B, len(pos) ** 3, cout).contiguous()
 
 
 class SingleConv(PackedModule, nn.Sequential):
@@ -148,20 +164,25 @@ class SingleConv(PackedModule, nn.Sequential):
             cache, gen = param_cache(self, "_split_packs"), (self.conv.weight.device, self.conv.weight._version)
             wpack = cache.get(gen, mode, lambda: ops.pack_conv_weight_split(self.conv.weight, mode).to(self.conv.weight.device))
             cout, sp = self.conv.out_channels, {}
+            wino = src1 is None and _wino_ok(arith, src0, cout)
+            wwino = cache.get(gen, "wino", lambda: ops.pack_conv_weight_split_wino(self.conv.weight).to(self.conv.weight.device)) if wino else None
             if (sparse is not None and arith.sparse_first_conv and src1 is None and mode != ops.SPLIT_BF16X3 and src0.shape[-1] <= 384
                     and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * sparse["reach"]
-                    and (sparse["reach"] == 1 or sparse.get("small_in") is not None)):
+                    and (sparse["reach"] == 1 or sparse.get("small_in") is not None)
+                    # (the class constants must come from the kernel the real launch takes: a Winograd layer handed a small volume it cannot take
+                    #  -- 5^3, from a layer that ran in the direct form -- simply runs dense)
+                    and (not wino or sparse.get("small_in") is None or ops.wino_supported(src0.shape[-1], cout, sparse["small_in"].shape[1:4]))):
                 B, reach = src0.shape[0], int(sparse["reach"])
                 small_in = sparse.get("small_in")
                 if small_in is None:
-                    small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-                ncls = (2 * reach + 1) ** 3
-                small_out = ops.conv3d_gcr_split(small_in, None, a, d, wpack, cout, relu=True, act_inv=act_inv)      # (a plain dense launch)
-                # class -> voxel of the 5^3 volume: reach 1 = voxels 0 / 2 / 4 per axis, reach 2 = all five (strided views: nothing is
-                # copied from the host, so the path can be captured into a HIP graph)
-                step = 2 if reach == 1 else 1
-                kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
-                sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
+                    n = 8 if wino else 5          # the Winograd kernel takes whole 4 x 8 x 8 tiles
+                    small_in = torch.zeros((B, n, n, n, src0.shape[-1]), dtype=torch.float32, device=src0.device)
+                # (a plain dense launch of the kernel the real launch takes)
+                if wino:
+                    small_out = ops.conv3d_gcr_split_wino(small_in, a, d, wwino, cout, relu=True, act_inv=act_inv)
+                else:
+                    small_out = ops.conv3d_gcr_split(small_in, None, a, d, wpack, cout, relu=True, act_inv=act_inv)
+                sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=_class_constants(small_out, reach, cout), kreach=reach)
                 sparse["small_out"] = small_out
             if src1 is not None and arith.polyphase_upconv and mode != ops.SPLIT_BF16X3 and src1.shape[-1] <= 384:
                 # polyphase form: the nearest-upsampled channels as a 2x2x2-tap convolution per output parity class on the COARSE volume
@@ -184,9 +205,8 @@ class SingleConv(PackedModule, nn.Sequential):
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)
                 return r if with_stats else (r, None)
-            if src1 is None and not sp and _wino_ok(arith, src0, cout):
-                wwino = cache.get(gen, "wino", lambda: ops.pack_conv_weight_split_wino(self.conv.weight).to(self.conv.weight.device))
-                r = ops.conv3d_gcr_split_wino(src0, a, d, wwino, cout, relu=True, with_stats=with_stats, act_inv=act_inv)
+            if wino:
+                r = ops.conv3d_gcr_split_wino(src0, a, d, wwino, cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
                 return r if with_stats else (r, None)
             r = ops.conv3d_gcr_split(src0, src1, a, d, wpack, cout, relu=True, with_stats=with_stats, act_inv=act_inv, **sp)
             return r if with_stats else (r, None)
@@ -214,14 +234,14 @@ class SingleConv(PackedModule, nn.Sequential):
         if (arith.sparse_first_conv and src0.shape[-1] <= 384 and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * reach
                 and (reach == 1 or small_in is not None)):
             if small_in is None:
-                small_in = torch.zeros((B, 5, 5, 5, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-            ncls = (2 * reach + 1) ** 3
-            # (a plain dense launch; the Winograd pack cannot serve a 5^3 volume: the class constants come from the direct form's pack -- away from
-            #  the cells the operand is exactly zero in either form, so they are the same numbers)
-            small_out = ops.conv3d_gcr_split_persample(small_in, ops.conv_affine_pack(w, a, d, st0, rest) if wino else prep, relu=True)
-            step = 2 if reach == 1 else 1
-            kconst = small_out[:, ::step, ::step, ::step].reshape(B, ncls, cout).contiguous()
-            sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=kconst, kreach=reach)
+                n = 8 if wino else 5              # the Winograd kernel takes whole 4 x 8 x 8 tiles
+                small_in = torch.zeros((B, n, n, n, src0.shape[-1]), dtype=torch.float32, device=src0.device)
+            # a plain dense launch over the small all-at-rest volume.  (A Winograd pack cannot serve a 5^3 volume handed down by a layer that ran in
+            # the direct form: the constants then come from the direct form's pack -- away from the cells the operand is exactly zero in either
+            # form, so they are the same numbers)
+            small_prep = prep if (not wino or ops.wino_supported(src0.shape[-1], cout, small_in.shape[1:4])) else ops.conv_affine_pack(w, a, d, st0, rest)
+            small_out = ops.conv3d_gcr_split_persample(small_in, small_prep, relu=True)
+            sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=_class_constants(small_out, reach, cout), kreach=reach)
             sparse["small_out"] = small_out
         r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, **sp)
         return r if with_stats else (r, None)

@@ -595,6 +595,80 @@ def test_unet_against_reference_module(golden_dir, name):
     assert np.abs(y - y64).max() <= 2 * max(np.abs(g["y"] - y64).max(), 2.5e-5)   # as accurate as the reference's own fp32 path
 
 
+@pytest.mark.parametrize("B,dims,C0,Cout,scattered", [(2, (8, 16, 16), 32, 128, False), (2, (8, 16, 16), 32, 128, True), (1, (4, 8, 8), 128, 128, False),
+                                                      (2, (12, 8, 24), 64, 256, False), (1, (16, 16, 16), 128, 128, True), (1, (8, 8, 40), 256, 128, False)])
+def test_conv3d_winograd_against_fp64(B, dims, C0, Cout, scattered):
+    """Winograd F(2,3)-along-x form of the 128-wide conv (gn_conv3d_gcr_split_wino, csrc/unet_wino.hip; layer: components/unet3d.py:53-76): both
+    operand forms -- literal (static transformed pack) and affine-in-weights (gn_conv_affine_pack_wino) -- against torch in fp64, next to the direct
+    f16x2 form and the fp32-MFMA kernel.  The bar is the f16x2 contract: error <= 2x the fp32-MFMA kernel's.  Volumes of one or two tiles per axis:
+    every voxel sits on a face somewhere (the border-class bias table and the zero padding of the transformed halo)."""
+    g = torch.Generator().manual_seed(C0 + Cout + dims[2])
+    D, H, W = dims
+    x = torch.randn(B, C0, D, H, W, generator=g)
+    if scattered:
+        x = x * (torch.rand(B, 1, D, H, W, generator=g) < 0.05)
+    w = torch.randn(Cout, C0, 3, 3, 3, generator=g) / (27 * C0) ** 0.5
+    gamma, beta = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
+    ref = F.relu(F.conv3d(F.group_norm(x.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1))
+    s0 = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    st = ops.channel_stats(s0)
+    a, d, inv = ops.groupnorm_affine(st, None, 8, 1e-5, gamma.to(DEV), beta.to(DEV), with_act_scale=True)
+    a0, d0 = ops.groupnorm_affine(st, None, 8, 1e-5, gamma.to(DEV), beta.to(DEV))
+    cl = lambda t: t.permute(0, 4, 1, 2, 3).cpu().double()
+    err = lambda t: float((cl(t) - ref).abs().max())
+    e32 = err(ops.conv3d_gcr(s0, None, a0, d0, ops.pack_conv_weight(w).to(DEV), Cout))
+    e_dir = err(ops.conv3d_gcr_split(s0, None, a, d, ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV), Cout, act_inv=inv))
+    yw, (sm, sq, V) = ops.conv3d_gcr_split_wino(s0, a, d, ops.pack_conv_weight_split_wino(w).to(DEV), Cout, act_inv=inv, with_stats=True)
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino_kernel<true>"
+    wd = w.to(DEV).contiguous()
+    prep = ops.conv_affine_pack(wd, a0, d0, st, wino=True)
+    yr, (smr, sqr, _) = ops.conv3d_gcr_split_persample(s0, prep, with_stats=True)
+    e_w, e_r = err(yw), err(yr)
+    print(f"B={B} {dims} {C0}->{Cout} {'scattered' if scattered else 'dense'}: err vs fp64: fp32-MFMA {e32:.2e}, direct f16x2 {e_dir:.2e}, Winograd literal {e_w:.2e}, "
+          f"Winograd affine-in-weights {e_r:.2e}")
+    bar = 2 * max(e32, 2e-6)
+    assert e_w <= bar and e_r <= bar
+    for y, s_, q_ in ((yw, sm, sq), (yr, smr, sqr)):                       # the epilogue statistics are those of the stored values
+        assert float((s_.cpu() - y.double().sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(s_.abs().max()))
+        assert float((q_.cpu() - (y.double() ** 2).sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(q_.abs().max()))
+    # run-to-run bit-identity
+    assert torch.equal(yr, ops.conv3d_gcr_split_persample(s0, prep))
+
+
+def test_conv3d_winograd_occupancy_aware_launch_and_shape_contract():
+    """(1) the occupancy-aware launch of the Winograd kernel (active-tile list + border-class constants from the DIRECT form's 5^3 launch: away from
+    the cells the operand is exactly zero in either form) is bit-identical to its dense launch; (2) shapes outside the kernel's contract are
+    refused with GN_EINVAL (ValueError), never run"""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(21)
+    B, G, C = 4, 32, 32
+    conv = SingleConv(C, 128).to(DEV)
+    conv.load_state_dict({k: S.synthetic_tensor("wn." + k, tuple(v.shape), 4).to(DEV) for k, v in conv.state_dict().items()})
+    x = torch.zeros(B, G, G, G, C)
+    n = 40
+    idx = torch.randint(0, G, (B - 1, n, 3), generator=g)
+    for b in range(B - 1):
+        x[b, idx[b, :, 0], idx[b, :, 1], idx[b, :, 2]] = torch.randn(n, C, generator=g).abs() * 2.0
+    flat = torch.cat([((b * G + idx[b, :, 0]) * G + idx[b, :, 1]) * G + idx[b, :, 2] for b in range(B - 1)]).to(torch.int32).to(DEV)
+    xg = x.to(DEV)
+    ar = AR.DEFAULT.replace(conv_mode=AR.SPLIT_F16X2, affine_in_weights=True, winograd=True)
+    y_d, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False))
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino_kernel<true>"
+    y_s, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=True))
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino_kernel<true>"
+    assert torch.equal(y_s, y_d) and bool(torch.isfinite(y_d).all()) and float(y_d.abs().max()) > 0
+    y_direct, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False, winograd=False))
+    assert float((y_direct - y_d).abs().max()) <= 2e-5 * max(1.0, float(y_d.abs().max()))
+    # shape contract
+    w = torch.randn(128, 32, 3, 3, 3, generator=g) * 0.05
+    pk = ops.pack_conv_weight_split_wino(w).to(DEV)
+    for dims in ((8, 8, 12), (6, 8, 8), (8, 12, 8)):
+        s0 = torch.randn(1, *dims, 32, generator=g).to(DEV)
+        with pytest.raises(ValueError):
+            ops.conv3d_gcr_split_wino(s0, torch.ones(1, 32, device=DEV), torch.zeros(1, 32, device=DEV), pk, 128)
+    assert not ops.wino_supported(32, 64, (8, 8, 8)) and not ops.wino_supported(272, 128, (8, 8, 8)) and ops.wino_supported(256, 256, (4, 8, 8))
+
+
 CONV_ORDERS = ("gcr", "cr", "crg", "cl", "ce", "bcr", "cbr", "cgr")
 
 

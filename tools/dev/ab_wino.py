@@ -88,3 +88,6 @@ if what == 'prof_scattered':
     bench(8, 128, 128, 128, 'scattered', reps=3, only='at-rest')
 if what == 'prof_randn':
     bench(8, 128, 128, 128, 'randn', reps=3, only='literal')
+if what == 'abl':                     # timing only (ablation builds give wrong results): the at-rest form on scattered and N(0,1) operands
+    bench(8, 128, 128, 128, 'scattered', reps=6, only='at-rest')
+    bench(8, 128, 128, 128, 'randn', reps=6, only='at-rest')
