@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 exec < /dev/null                            # nothing below may wait on stdin
 # one stream: counter collection serialises kernels anyway, and per-kernel rows are easier to read
 export GARMENTNETS_PREFETCH_ZERO=0
-BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strict-pass --no-host-io-pass --no-validate --no-occupancy-pass $*"
+BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strict-pass --no-host-io-pass --no-validate --no-occupancy-pass --no-in-flight-pass --no-latency-b1 --no-pmc $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$RAW/fetch" -o pmc -- $BENCH > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$RAW/write" -o pmc -- $BENCH > "$OUT/write.log" 2>&1
