@@ -434,6 +434,199 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
 // (they had four stages = 24 x 4 MFMAs to arrive).  The wrap-around (stage (t+4) % NSTAGE belongs to the NEXT tile; the last tile
 // fetches four stages it never uses) keeps every count independent of the tile.
 
+// ------------------------------------------------------------------------------------------------ [32, 512, 512, OUT]: the class-default hidden width
+// ImplicitWNFDecoder's constructor default is nn_channels = (128, 512, 512, 1) (networks/conv_implicit_wnf.py:122); with the UNet's final 1x1x1
+// convolution folded into the first layer (folded_pack) that is a [32, 512, 512, OUT] chain.  Same transposed register chain, same arithmetic and
+// scaling as implicit_decode_split_kernel, laid out for 16 blocks of 32 hidden units per layer:
+//  * one wave per SIMD (the layer-1 activations are 2 planes x 32 k-groups = 256 registers), 128 queries per workgroup pass, persistent workgroups;
+//  * layer 1 (8 block pairs x 2 k-groups) fully unrolled -- its epilogue writes the layer-2 operand registers, whose indices must be static;
+//    layer 2 (8 pairs x 32 k-groups) as a RUNTIME loop over pairs of block pairs (4 iterations x 64 unrolled steps = 384 MFMAs per body, the size
+//    of the 256-wide kernel's whole tile): a pair's 8 stages are a multiple of the 4-stage ring, so every ring slot stays a compile-time constant;
+//  * two accumulator sets: the epilogue of block pair P (bias, ReLU, output-layer partial sums) rides along the MFMAs of pair P+1;
+//  * weights: 68 stages of 16 KB per tile (1.06 MB, L2-resident) through the same 4-stage LDS ring, global_load_lds three stages ahead, one counted
+//    wait + raw barrier per stage.  The next tile's rows are ordinary loads issued at the start of the last loop iteration: hipcc's own vmcnt wait at
+//    their first use can only be stricter than needed (VM operations retire in order), never too lenient.
+template <int OUTC>
+__global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSplitArgs p) {
+    constexpr int NH = 512, NB = NH / 32, NPAIR = NB / 2, KG2 = NH / 16, K0G = 2;
+    constexpr int TAB1 = NB * 2 * 16, TAB2 = NB * 2 * (1 + OUTC) * 16, TABN = TAB1 + TAB2 + 3 * OUTC;
+    constexpr int NS1 = NPAIR * K0G, NSTAGE1 = NS1 / 4, NSTAGE = NSTAGE1 + NPAIR * KG2 / 4;      // 4 + 64 stages
+    constexpr int TAB_BYTES = ((TABN * 4 + 15) / 16) * 16;
+    static_assert(NSTAGE1 % DS_RING == 0 && (KG2 / 4) % DS_RING == 0, "ring slots must be compile-time constants");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DS_RING * DS_STAGE_BYTES + TAB_BYTES];
+    float *const tab = reinterpret_cast<float *>(smem + DS_RING * DS_STAGE_BYTES);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
+
+    if (p.xscale && p.xscale[2] != 0.f) return;     // wave-uniform: the whole grid leaves (gn_decoder_input_scale's verdict)
+    const float sx = p.xscale ? p.xscale[0] : 1.f, inv_sx = p.xscale ? p.xscale[1] : 1.f;
+    for (int i = tid; i < TABN; i += 256) {          // the bias entries enter in the scaled units of the chain
+        const bool bias = i < TAB1 || (i < TAB1 + TAB2 && ((i - TAB1) / 16) % (1 + OUTC) == 0);
+        tab[i] = bias ? __fmul_rn(p.tab[i], sx) : p.tab[i];
+    }
+    const unsigned char *wsrc = p.wp + (wave * 4) * 1024;
+    const unsigned lane16 = lane * 16;
+    // stage `st` (0 .. NSTAGE-1, wrapping into the next tile) -> ring slot `slot`
+    auto issue = [&](int st, int slot) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            ds_glds16_s(wsrc + (size_t)st * DS_STAGE_BYTES + c * 1024, lane16, lds_base + slot * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
+    };
+    issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
+
+    float4 raw[4];
+    {
+        long long m = (long long)blockIdx.x * DS_TILE + wave * 32 + r;
+        if (m >= p.M) m = p.M - 1;
+        const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+        raw[0] = row[0]; raw[1] = row[1]; raw[2] = row[4]; raw[3] = row[5];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): prologue DMAs + table stores
+    __syncthreads();
+
+    const unsigned char *const ring_rd = smem + lane * 16;
+    uint4 A[4], nA[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + f * 1024);
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint4 x0[2][K0G], h1[2][KG2];
+#pragma unroll
+        for (int g = 0; g < K0G; ++g) {
+            ds_split2(__fmul_rn(raw[2 * g].x, sx), __fmul_rn(raw[2 * g].y, sx), x0[0][g].x, x0[1][g].x);
+            ds_split2(__fmul_rn(raw[2 * g].z, sx), __fmul_rn(raw[2 * g].w, sx), x0[0][g].y, x0[1][g].y);
+            ds_split2(__fmul_rn(raw[2 * g + 1].x, sx), __fmul_rn(raw[2 * g + 1].y, sx), x0[0][g].z, x0[1][g].z);
+            ds_split2(__fmul_rn(raw[2 * g + 1].z, sx), __fmul_rn(raw[2 * g + 1].w, sx), x0[0][g].w, x0[1][g].w);
+        }
+        float psum[OUTC];
+#pragma unroll
+        for (int o = 0; o < OUTC; ++o) psum[o] = 0.f;
+        f32x16q acc[2][2];
+
+        // one k-group step: stage slot `slot` (compile-time), k-group slot kg inside it; `next_stage` = the stage to request at a hand-over (kg == 3)
+        auto step = [&](int kg, int slot, int next_stage, const uint4 &b1, const uint4 &b2, f32x16q (&ac)[2]) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) A[f] = nA[f];
+            if (kg < 3) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + slot * DS_STAGE_BYTES + ((kg + 1) * 4 + f) * 1024);
+            } else {
+                // hand-over: the next stage has landed for everybody (VM queue: three stages of four pieces; at most 8 may remain), this stage has
+                // been read by everybody -> its slot takes the stage three ahead
+                DS_WAIT_VM_LGKM0(8);
+                __builtin_amdgcn_s_barrier();
+                issue(next_stage, slot);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) nA[f] = *reinterpret_cast<const uint4 *>(ring_rd + ((slot + 1) % DS_RING) * DS_STAGE_BYTES + f * 1024);
+            }
+            ac[0] = ds_mfma(A[1], b1, ac[0]);
+            ac[1] = ds_mfma(A[3], b1, ac[1]);
+            ac[0] = ds_mfma(A[0], b2, ac[0]);
+            ac[1] = ds_mfma(A[2], b2, ac[1]);
+            ac[0] = ds_mfma(A[0], b1, ac[0]);
+            ac[1] = ds_mfma(A[2], b1, ac[1]);
+        };
+        // layer-1 epilogue of registers [4 qd, 4 qd + 4) of both blocks of pair P -> the layer-2 operand planes (k-groups 2 nb, 2 nb + 1)
+        auto epi1 = [&](int P, int qd, f32x16q (&ac)[2]) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int nb = 2 * P + blk;
+                const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
+                const float v0 = gn_relu(__fadd_rn(ac[blk][4 * qd + 0], bv.x)), v1 = gn_relu(__fadd_rn(ac[blk][4 * qd + 1], bv.y));
+                const float v2 = gn_relu(__fadd_rn(ac[blk][4 * qd + 2], bv.z)), v3 = gn_relu(__fadd_rn(ac[blk][4 * qd + 3], bv.w));
+                const int g2 = 2 * nb + (qd >> 1);
+                if (qd & 1) {
+                    ds_split2(v0, v1, h1[0][g2].z, h1[1][g2].z);
+                    ds_split2(v2, v3, h1[0][g2].w, h1[1][g2].w);
+                } else {
+                    ds_split2(v0, v1, h1[0][g2].x, h1[1][g2].x);
+                    ds_split2(v2, v3, h1[0][g2].y, h1[1][g2].y);
+                }
+            }
+        };
+        // layer-2 epilogue of pair P2 (runtime): bias, ReLU, output-layer partial sums
+        auto epi2 = [&](int P2, int qd, f32x16q (&ac)[2]) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int nb = 2 * P2 + blk;
+                const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
+                const float4 bv = *reinterpret_cast<const float4 *>(tb);
+                const float v0 = gn_relu(__fadd_rn(ac[blk][4 * qd + 0], bv.x)), v1 = gn_relu(__fadd_rn(ac[blk][4 * qd + 1], bv.y));
+                const float v2 = gn_relu(__fadd_rn(ac[blk][4 * qd + 2], bv.z)), v3 = gn_relu(__fadd_rn(ac[blk][4 * qd + 3], bv.w));
+#pragma unroll
+                for (int o = 0; o < OUTC; ++o) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
+                    psum[o] = fmaf(v0, wv.x, psum[o]);
+                    psum[o] = fmaf(v1, wv.y, psum[o]);
+                    psum[o] = fmaf(v2, wv.z, psum[o]);
+                    psum[o] = fmaf(v3, wv.w, psum[o]);
+                }
+            }
+        };
+        auto zero = [&](f32x16q (&ac)[2]) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ac[0][q] = 0.f; ac[1][q] = 0.f; }
+        };
+
+        // ---- layer 1: pairs 0 .. 7, two k-groups each; pair P's epilogue rides along pair P+1's two steps (two register quads per step)
+#pragma unroll
+        for (int s1 = 0; s1 < NS1; ++s1) {
+            const int P = s1 / K0G, g = s1 % K0G, t = s1 >> 2, kg = s1 & 3, set = P & 1;
+            if (g == 0) zero(acc[set]);
+            step(kg, t % DS_RING, t + DS_RING, x0[0][g], x0[1][g], acc[set]);
+            if (P > 0) { epi1(P - 1, 2 * g, acc[set ^ 1]); epi1(P - 1, 2 * g + 1, acc[set ^ 1]); }
+        }
+        // ---- layer 2: iteration `it` = block pairs 2 it (accumulator set 0) and 2 it + 1 (set 1); stage of its step s2: NSTAGE1 + it * 16 + (s2 >> 2)
+        for (int it = 0; it < NPAIR / 2; ++it) {
+            if (it == NPAIR / 2 - 1) {               // next tile's rows (clamped: the last tile re-reads its own)
+                long long tn = tile + gridDim.x;
+                if (tn >= ntiles) tn = tile;
+                long long m = tn * DS_TILE + wave * 32 + r;
+                if (m >= p.M) m = p.M - 1;
+                const float4 *row = reinterpret_cast<const float4 *>(p.xin + m * p.ldxin + 8 * h);
+                raw[0] = row[0]; raw[1] = row[1]; raw[2] = row[4]; raw[3] = row[5];
+            }
+            const int tbase = NSTAGE1 + it * (2 * KG2 / 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * KG2; ++s2) {
+                const int half = s2 / KG2, g = s2 % KG2, tl = s2 >> 2, kg = s2 & 3;
+                if (g == 0) zero(acc[half]);
+                int nxt = tbase + tl + DS_RING;      // (runtime: wraps into the next tile's first stages)
+                if (nxt >= NSTAGE) nxt -= NSTAGE;
+                step(kg, tl % DS_RING, nxt, h1[0][g], h1[1][g], acc[half]);
+                // the previous pair's epilogue, one register quad per step over the first four steps: layer 1's last pair under the very first
+                // layer-2 pair, then layer-2 pair (2 it + half - 1)
+                if (g < 4) {
+                    if (half == 0) {
+                        if (it == 0) epi1(NPAIR - 1, g, acc[1]);
+                        else epi2(2 * it - 1, g, acc[1]);
+                    } else {
+                        epi2(2 * it, g, acc[0]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) epi2(NPAIR - 1, qd, acc[1]);
+        // ---- output layer: the two lane halves hold disjoint unit sets of the same query
+        const long long m = tile * DS_TILE + wave * 32 + r;
+#pragma unroll
+        for (int o = 0; o < OUTC; ++o) {
+            const float s = psum[o] + __shfl_xor(psum[o], 32);
+            if (h == 0 && m < p.M) {
+                const float *t3 = tab + TAB1 + TAB2;
+                float y = gn_relu(__fadd_rn(__fmul_rn(s, inv_sx), t3[o]));
+                y = __fadd_rn(__fmul_rn(y, t3[OUTC + o]), t3[2 * OUTC + o]);
+                p.out[m * p.ldo + o] = y;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);              // the wrapped-around DMAs must land before the LDS goes away
+    __syncthreads();
+}
+
 // the garment's input scale from the per-channel sums of squares of the volume the rows are sampled from (= the statistics the last
 // conv's epilogue emitted): s = 2^k with (largest channel rms) * s in [1, 2), clamped to smax (the pack's bound that keeps the scaled
 // biases below 2^13).  When the clamp costs more than 2^4 the rows would be split below their natural scale (a checkpoint whose biases
@@ -494,7 +687,9 @@ extern "C" int gn_implicit_decode_lattice_split(const float *vol, int D, int H, 
 extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                                         int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
     GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
-    GN_REQUIRE((C0 == 128 || C0 == 32) && N1 == DS_N && N2 == DS_N, "gn_implicit_decode_split: only [128 | 32, 256, 256, out] decoders are packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
+    const bool wide512 = C0 == 32 && N1 == 512 && N2 == 512;
+    GN_REQUIRE(wide512 || ((C0 == 128 || C0 == 32) && N1 == DS_N && N2 == DS_N),
+               "gn_implicit_decode_split: only [128 | 32, 256, 256, out] and [32, 512, 512, out] decoders are packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
     GN_REQUIRE(ldxin >= C0 && ldxin % 4 == 0, "gn_implicit_decode_split: rows need a 16-byte aligned leading dimension");
     if (M == 0) return GN_OK;
     GN_REQUIRE(xin && wpack && tab && out, "gn_implicit_decode_split: null pointer");
@@ -505,6 +700,17 @@ extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, 
     const int64_t slots = (C0 == 32 && OUT == 1) ? 512 : 256;                       // persistent workgroups: two per CU when they fit (K0G = 2), else one
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     hipStream_t st = gn_stream(stream);
+    if (wide512) {
+        const unsigned g512 = (unsigned)(ntiles < 256 ? ntiles : 256);
+        switch (OUT) {
+            case 1: hipLaunchKernelGGL((implicit_decode_split512_kernel<1>), dim3(g512), dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((implicit_decode_split512_kernel<2>), dim3(g512), dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((implicit_decode_split512_kernel<3>), dim3(g512), dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((implicit_decode_split512_kernel<4>), dim3(g512), dim3(256), 0, st, p); break;
+        }
+        GN_LAUNCH_CHECK("gn_implicit_decode_split");
+        return GN_OK;
+    }
 #define DS_LAUNCH(O)                                                                                                           \
     do {                                                                                                                       \
         if (C0 == 128) hipLaunchKernelGGL((implicit_decode_split_kernel<O, 8>), dim3(grid), dim3(256), 0, st, p);              \

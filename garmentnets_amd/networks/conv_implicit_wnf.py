@@ -193,7 +193,8 @@ class ImplicitWNFDecoder(PackedModule):
                 sc, sh = fold_batchnorm(block[2]) if len(block) > 2 else (None, None)
                 layers.append((ops.pack_kpair(w) if i < 2 else w.contiguous(), b, sc, sh, ch[i + 1]))
                 raw.append((w, b, sc, sh))
-            split = ops.pack_decode_split(raw).to(w.device) if (final_conv.in_channels, ch[1], ch[2]) == (32, 256, 256) else None
+            # the split-operand pack: the shipped hidden width 256 and the class default 512 (conv_implicit_wnf.py:122), csrc/decode_split.hip
+            split = ops.pack_decode_split(raw).to(w.device) if (final_conv.in_channels, ch[1], ch[2]) in ((32, 256, 256), (32, 512, 512)) else None
             return tuple(layers) + (split,)
         return param_cache(self, "_folded").get(key, "folded", build)
 

@@ -613,11 +613,11 @@ class DecodeSplitPack:
     """weights / epilogue tables of gn_implicit_decode_split for one [128 | 32, 256, 256, OUT] decoder; smax: upper bound for the run-time
     input scale (keeps the scaled biases small, see pack_decode_split)"""
 
-    def __init__(self, wpack, tab, smax, out_channels):
-        self.wpack, self.tab, self.smax, self.out_channels = wpack, tab, float(smax), int(out_channels)
+    def __init__(self, wpack, tab, smax, out_channels, hidden=256):
+        self.wpack, self.tab, self.smax, self.out_channels, self.hidden = wpack, tab, float(smax), int(out_channels), int(hidden)
 
     def to(self, device):
-        return DecodeSplitPack(self.wpack.to(device), self.tab.to(device), self.smax, self.out_channels)
+        return DecodeSplitPack(self.wpack.to(device), self.tab.to(device), self.smax, self.out_channels, self.hidden)
 
 
 def _pow2_floor_inv(m):
@@ -632,24 +632,26 @@ def _d_unit(q, h):
 
 
 def pack_decode_split(layers):
-    """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)) with w1 (256,128), w2 (256,256), w3 (OUT,256) fp32, s/t = folded
-    BatchNorm scale/shift or None -> DecodeSplitPack.  The BatchNorm affine of hidden layer i is folded into layer i+1
-    (W' = W diag(s), b' = b + W t, in fp64).  Every hidden unit j carries a static power-of-two scale r_j (its weight row's maximum
-    scaled into [1, 2)): the kernel keeps hidden activations in those units (r_j * s_x * h_j, s_x = the garment's run-time input scale)
-    and 1 / r_j is folded into the next layer's column j -- all exact.  Weight stages: [24][4 k-groups][2 blocks][2 planes][64 lanes]
-    [8 fp16]; layer 2's k order follows the register layout the layer-1 accumulators already have (see csrc/decode_split.hip).  w1 may
-    be (256, 32): the first layer with the UNet's final 1x1x1 convolution folded in (ImplicitWNFDecoder.folded_pack)."""
+    """layers = ((w1,b1,s1,t1), (w2,b2,s2,t2), (w3,b3,s3,t3)) with w1 (N,128) or (N,32), w2 (N,N), w3 (OUT,N) fp32, N = 256 (the shipped decoders) or 512
+    (the class default, networks/conv_implicit_wnf.py:122; 32-channel folded input only), s/t = folded BatchNorm scale/shift or None -> DecodeSplitPack.
+    The BatchNorm affine of hidden layer i is folded into layer i+1 (W' = W diag(s), b' = b + W t, in fp64).  Every hidden unit j carries a static
+    power-of-two scale r_j (its weight row's maximum scaled into [1, 2)): the kernel keeps hidden activations in those units (r_j * s_x * h_j, s_x =
+    the garment's run-time input scale) and 1 / r_j is folded into the next layer's column j -- all exact.  Weight stages of 16 KB:
+    [4 k-groups][2 blocks][2 planes][64 lanes][8 fp16], steps in (block pair, k-group) order, layer 1 then layer 2; layer 2's k order follows the
+    register layout the layer-1 accumulators already have (see csrc/decode_split.hip).  w1 (N, 32): the first layer with the UNet's final 1x1x1
+    convolution folded in (ImplicitWNFDecoder.folded_pack)."""
     (w1, b1, s1, t1), (w2, b2, s2, t2), (w3, b3, s3, t3) = layers
     dd = lambda v, n, fill: (torch.full((n,), fill, dtype=torch.float64) if v is None else v.detach().double().cpu())
     w1, w2, w3 = w1.detach().double().cpu(), w2.detach().double().cpu(), w3.detach().double().cpu()
-    out_c = w3.shape[0]
-    assert w1.shape in ((256, 128), (256, 32)) and w2.shape == (256, 256) and w3.shape[1] == 256 and 1 <= out_c <= 4
-    k0g = w1.shape[1] // 16                                                                       # 16-deep k-groups of layer 1
-    b2f = dd(b2, 256, 0.0) + w2 @ dd(t1, 256, 0.0)
-    w2 = w2 * dd(s1, 256, 1.0)[None, :]
-    b3f = (dd(b3, out_c, 0.0) + w3 @ dd(t2, 256, 0.0)).float()
-    w3 = w3 * dd(s2, 256, 1.0)[None, :]
-    b1f = dd(b1, 256, 0.0)
+    out_c, N = w3.shape[0], w2.shape[0]
+    assert N in (256, 512) and w1.shape[0] == N and w2.shape == (N, N) and w3.shape[1] == N and 1 <= out_c <= 4
+    assert w1.shape[1] in ((128, 32) if N == 256 else (32,)), "the 512-wide pack takes the folded 32-channel first layer"
+    k0g, npair, nb_, kg2 = w1.shape[1] // 16, N // 64, N // 32, N // 16                           # 16-deep k-groups of layer 1; block pairs, blocks, k-groups of layer 2
+    b2f = dd(b2, N, 0.0) + w2 @ dd(t1, N, 0.0)
+    w2 = w2 * dd(s1, N, 1.0)[None, :]
+    b3f = (dd(b3, out_c, 0.0) + w3 @ dd(t2, N, 0.0)).float()
+    w3 = w3 * dd(s2, N, 1.0)[None, :]
+    b1f = dd(b1, N, 0.0)
     # per-unit scales (exact powers of two); a weight or bias that leaves fp32's range through them would be a broken checkpoint anyway
     r1 = _pow2_floor_inv(w1.abs().amax(dim=1))
     w1s, b1s = (w1 * r1[:, None]).float(), (b1f * r1).float()
@@ -661,12 +663,11 @@ def pack_decode_split(layers):
     bmax = max(float(b1s.abs().max()), float(b2s.abs().max()))
     smax = 2.0 ** 60 if not (bmax > 0 and math.isfinite(bmax)) else min(2.0 ** 60, 2.0 ** math.floor(math.log2(8192.0 / bmax)))
     ar = torch.arange
-    bp, g1, blk, h, r, i = torch.meshgrid(ar(4), ar(k0g), ar(2), ar(2), ar(32), ar(8), indexing="ij")
+    bp, g1, blk, h, r, i = torch.meshgrid(ar(npair), ar(k0g), ar(2), ar(2), ar(32), ar(8), indexing="ij")
     a1 = w1s[32 * (2 * bp + blk) + r, 16 * g1 + 8 * h + i]                                       # [pair][k-group][blk][h][r][i]
-    bp, kq, kg, blk, h, r, i = torch.meshgrid(ar(4), ar(4), ar(4), ar(2), ar(2), ar(32), ar(8), indexing="ij")
-    g2 = 4 * kq + kg
+    bp, g2, blk, h, r, i = torch.meshgrid(ar(npair), ar(kg2), ar(2), ar(2), ar(32), ar(8), indexing="ij")
     q = 8 * (g2 & 1) + i
-    a2 = w2s[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]
+    a2 = w2s[32 * (2 * bp + blk) + r, 32 * (g2 >> 1) + (q & 3) + 8 * (q >> 2) + 4 * h]          # [pair][k-group][blk][h][r][i]
 
     def planes(a):                                   # [..steps..][blk][h][r][i] -> [stage][4 steps][blk][plane][h][r][i]
         p1 = a.to(torch.float16)
@@ -674,15 +675,15 @@ def pack_decode_split(layers):
         st = torch.stack((p1, p2), dim=-4)                                                        # [...][blk][plane][h][r][i]
         return st.reshape(-1, 4, 2, 2, 2, 32, 8)                                                  # steps in (pair, k-group) order, 4 per stage
 
-    wpack = torch.cat((planes(a1), planes(a2)), dim=0).contiguous().view(torch.int16)             # [k0g + 16 stages][...]
-    assert wpack.numel() * 2 == (k0g + 16) * 16384
-    nb, hh, qq = torch.meshgrid(ar(8), ar(2), ar(16), indexing="ij")
-    u = 32 * nb + (qq & 3) + 8 * (qq >> 2) + 4 * hh                                               # [8][2][16]
+    wpack = torch.cat((planes(a1), planes(a2)), dim=0).contiguous().view(torch.int16)             # [(npair * (k0g + kg2)) / 4 stages][...]
+    assert wpack.numel() * 2 == npair * (k0g + kg2) // 4 * 16384
+    nb, hh, qq = torch.meshgrid(ar(nb_), ar(2), ar(16), indexing="ij")
+    u = 32 * nb + (qq & 3) + 8 * (qq >> 2) + 4 * hh                                               # [blocks][2][16]
     tab1 = b1s[u]
-    tab2 = torch.stack([b2s[u]] + [w3s[o][u] for o in range(out_c)], dim=2)                       # [8][2][1+OUT][16]
+    tab2 = torch.stack([b2s[u]] + [w3s[o][u] for o in range(out_c)], dim=2)                       # [blocks][2][1+OUT][16]
     tail = torch.stack((b3f, dd(s3, out_c, 1.0).float(), dd(t3, out_c, 0.0).float()))
     tab = torch.cat((tab1.reshape(-1), tab2.reshape(-1), tail.reshape(-1))).float().contiguous()
-    return DecodeSplitPack(wpack, tab, smax, out_c)
+    return DecodeSplitPack(wpack, tab, smax, out_c, hidden=N)
 
 
 def decoder_input_scale(sumsq, V, smax):
@@ -702,7 +703,7 @@ def implicit_decode_split(xin, pack, out=None, xscale=None):
     if out is None:
         out = torch.empty((M, pack.out_channels), dtype=torch.float32, device=xin.device)
     _lib.call("gn_implicit_decode_split", _p(xin), rows_view(xin)[1], int(M), _p(pack.wpack), _p(pack.tab), _p(xscale),
-              C0, 256, 256, pack.out_channels, _p(out), rows_view(out)[1], _stream())
+              C0, pack.hidden, pack.hidden, pack.out_channels, _p(out), rows_view(out)[1], _stream())
     return out
 
 
@@ -718,7 +719,7 @@ def implicit_decode_lattice_split(vol_b, Q, pack, out, xscale=None, m0=0, M=None
 
 def lattice_split_supported(vol_b, pack):
     D, H, W, C0 = vol_b.shape
-    return C0 == 32 and pack.out_channels == 1 and D * H * W * 128 < 2 ** 32 and vol_b.is_contiguous()
+    return C0 == 32 and pack.out_channels == 1 and pack.hidden == 256 and D * H * W * 128 < 2 ** 32 and vol_b.is_contiguous()
 
 
 # ------------------------------------------------------------------------------------------------ isosurface

@@ -819,13 +819,15 @@ def test_fused_decoder_against_torch_and_unfused(out_ch, M, decode_mode):
     np.testing.assert_allclose(lat.reshape(2, -1, out_ch).cpu().numpy(), ref_lat.numpy(), rtol=1e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("k0", [128, 32])
+@pytest.mark.parametrize("k0,nh", [(128, 256), (32, 256), (32, 512)])
 @pytest.mark.parametrize("out_ch,M,bn", [(1, 70001, True), (3, 4100, True), (2, 129, False), (4, 128, True)])
-def test_decoder_split_against_fp64(out_ch, M, bn, k0):
+def test_decoder_split_against_fp64(out_ch, M, bn, k0, nh):
     """gn_implicit_decode_split (two fp16 planes per operand on the matrix cores, activations chained through registers, persistent
     workgroups) against an fp64 evaluation and against the fp32-MFMA kernel on the same rows: at least as accurate."""
-    g = torch.Generator().manual_seed(out_ch * 7 + M + k0)
-    dims = [k0, 256, 256, out_ch]                    # k0 = 32: the first layer with the UNet's final 1x1x1 conv folded in
+    g = torch.Generator().manual_seed(out_ch * 7 + M + k0 + nh)
+    # k0 = 32: the first layer with the UNet's final 1x1x1 conv folded in; nh = 512: the reference class's default hidden width
+    # (networks/conv_implicit_wnf.py:122), implicit_decode_split512_kernel
+    dims = [k0, nh, nh, out_ch]
     raw, ref = [], None
     x = torch.randn(M, k0, generator=g) * 2.0
     x[0] = 0.0
@@ -846,7 +848,7 @@ def test_decoder_split_against_fp64(out_ch, M, bn, k0):
     layers = tuple((ops.pack_kpair(w).to(DEV) if i < 2 else w.contiguous().to(DEV), b.to(DEV), dv(sc), dv(sh), dims[i + 1]) for i, (w, b, sc, sh) in enumerate(raw))
     out32 = ops.implicit_decode(None, layers, M=M, xin=xin)
     e_split, e_f32 = (out.cpu().double() - h).abs().max().item(), (out32.cpu().double() - h).abs().max().item()
-    print(f"decoder [{k0},256,256,{out_ch}] M={M}: err vs fp64 split {e_split:.2e}, fp32-MFMA {e_f32:.2e}, |y| max {h.abs().max():.2f}")
+    print(f"decoder [{k0},{nh},{nh},{out_ch}] M={M}: err vs fp64 split {e_split:.2e}, fp32-MFMA {e_f32:.2e}, |y| max {h.abs().max():.2f}")
     assert e_split <= max(2 * e_f32, 2e-6) and e_split <= 2e-5
 
 

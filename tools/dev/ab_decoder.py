@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from garmentnets_amd import ops
 dev = 'cuda'
 g = torch.Generator().manual_seed(5)
-dims = [32, 256, 256, 1]
+NH = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dims = [32, NH, NH, 1]
 raw = []
 for i in range(3):
     w = torch.randn(dims[i + 1], dims[i], generator=g) * (2.0 / dims[i]) ** 0.5 * (0.3 if i == 1 else 1.0)
@@ -18,5 +19,5 @@ for M in (1000, 2 ** 20, 2 ** 21 + 77, 16 * 2 ** 20):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); [ops.implicit_decode_split(xin, pack, out=out) for _ in range(reps)]; e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * (32 * 256 + 256 * 256 + 256) * M
+    fl = 2.0 * (32 * NH + NH * NH + NH) * M
     print(f'M={M}: {ms:.4f} ms {fl / ms / 1e9:.1f} TF(eq) digest {hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]}', flush=True)
