@@ -128,7 +128,7 @@ class SAModule(torch.nn.Module):
         self_src = None
         if self.conv.add_self_loops and self.conv.self_loop_scope == "example" and seg.num > 1:
             self_src = _example_self_src(seg.sizes, out_sizes, pos.device)
-        if pack is not None and x is not None and x.shape[1] == pack.cin:
+        if pack is not None and ((x is None and pack.cin == 0) or (x is not None and x.shape[1] == pack.cin)):
             # one kernel: gather -> edge MLP on the matrix cores -> BatchNorm -> max; no edge tensor in HBM (csrc/sa_fused.hip)
             out = ops.sa_fused(x, pos, idx, nbr, cnt, pack, self_loops=self.conv.add_self_loops, self_src=self_src)
         else:

@@ -238,8 +238,18 @@ static int sa_launch(const SaArgs &p, hipStream_t st) {
     return 0;
 }
 
+// Instantiated edge MLPs [C + 3, N1, N2, N3]: the two the GarmentNets checkpoints ship (first two rows) and the other PointNet++ set-abstraction shapes in
+// common use (round 5; the kernel template is generic in all four, an instantiation costs compile time only).  Anything else: the unfused chain.
+#define SA_SHAPES(X)                                                                                                           \
+    X(3, 64, 64, 128) X(128, 128, 128, 256)                                                                                    \
+    X(3, 32, 32, 64) X(3, 32, 64, 128) X(3, 64, 64, 64) X(3, 64, 128, 128)                                                     \
+    X(64, 64, 64, 128) X(64, 64, 128, 256) X(128, 128, 128, 128) X(128, 128, 256, 256) X(0, 64, 64, 128)
+
 extern "C" int gn_sa_fused_supported(int C, int N1, int N2, int N3) {
-    return (C == 3 && N1 == 64 && N2 == 64 && N3 == 128) || (C == 128 && N1 == 128 && N2 == 128 && N3 == 256);
+#define SA_MATCH(c, n1, n2, n3) if (C == c && N1 == n1 && N2 == n2 && N3 == n3) return 1;
+    SA_SHAPES(SA_MATCH)
+#undef SA_MATCH
+    return 0;
 }
 
 extern "C" int gn_sa_fused_scoped(const float *x, int ldx, int C, const float *pos, const int32_t *centre_idx, const int32_t *nbr,
@@ -247,7 +257,7 @@ extern "C" int gn_sa_fused_scoped(const float *x, int ldx, int C, const float *p
                                   const float *w2p, const float *w3p, const float *tab, int N1, int N2, int N3, float *out, int ldo,
                                   void *stream) {
     GN_REQUIRE(M >= 0 && K > 0 && K <= 64 && ldo >= N3, "gn_sa_fused: bad sizes (the ball-query table holds at most 64 neighbours)");
-    GN_REQUIRE(gn_sa_fused_supported(C, N1, N2, N3), "gn_sa_fused: edge MLP [%d+3,%d,%d,%d] is not instantiated (shipped: [6,64,64,128], [131,128,128,256]); use gn_sa_gather + gn_linear + gn_segment_max", C, N1, N2, N3);
+    GN_REQUIRE(gn_sa_fused_supported(C, N1, N2, N3), "gn_sa_fused: edge MLP [%d+3,%d,%d,%d] is not instantiated (see SA_SHAPES in csrc/sa_fused.hip); use gn_sa_gather + gn_linear + gn_segment_max", C, N1, N2, N3);
     GN_REQUIRE(C == 0 || (x && ldx >= C && (C < 8 || ldx % 4 == 0)), "gn_sa_fused: feature rows need a 16-byte aligned leading dimension");
     if (M == 0) return GN_OK;
     GN_REQUIRE(pos && centre_idx && nbr && cnt && w1p && w2p && w3p && tab && out, "gn_sa_fused: null pointer");
@@ -256,8 +266,9 @@ extern "C" int gn_sa_fused_scoped(const float *x, int ldx, int C, const float *p
     p.self_src = self_src;
     p.w1 = (const float4 *)w1p; p.w2 = (const float4 *)w2p; p.w3 = (const float4 *)w3p; p.tab = tab; p.out = out; p.ldo = ldo;
     hipStream_t st = gn_stream(stream);
-    if (C == 3) sa_launch<3, 64, 64, 128>(p, st);
-    else sa_launch<128, 128, 128, 256>(p, st);
+#define SA_DISPATCH(c, n1, n2, n3) if (C == c && N1 == n1 && N2 == n2 && N3 == n3) sa_launch<c, n1, n2, n3>(p, st);
+    SA_SHAPES(SA_DISPATCH)
+#undef SA_DISPATCH
     GN_LAUNCH_CHECK("gn_sa_fused");
     return GN_OK;
 }

@@ -1114,7 +1114,8 @@ def test_chamfer_against_ckdtree():
 
 
 # ------------------------------------------------------------------------------------------------ fused set abstraction
-@pytest.mark.parametrize("level", ["sa1", "sa2"])
+@pytest.mark.parametrize("level", ["sa1", "sa2", "3-32-64-128", "3-64-128-128", "3-32-32-64", "3-64-64-64", "64-64-64-128", "64-64-128-256", "128-128-128-128",
+                                   "128-128-256-256", "0-64-64-128"])
 @pytest.mark.parametrize("self_loops", [True, False])
 def test_sa_fused_against_unfused_chain(level, self_loops):
     """gn_sa_fused (gather -> edge MLP on the matrix cores -> BatchNorm -> max in one kernel) against the unfused chain
@@ -1128,16 +1129,23 @@ def test_sa_fused_against_unfused_chain(level, self_loops):
     if level == "sa1":
         cin, dims, ratio, rad = 3, [6, 64, 64, 128], 0.5, 0.05
         x = x0
-    else:
+    elif level == "sa2":
         cin, dims, ratio, rad = 128, [131, 128, 128, 256], 0.25, 0.1
         x = torch.randn(pos.shape[0], 128, generator=g)
+    else:        # round 5: the other instantiated edge MLPs (SA_SHAPES in csrc/sa_fused.hip), incl. a position-only one (no point features)
+        c, n1, n2, n3 = [int(v) for v in level.split("-")]
+        assert ops.sa_fused_supported(c, [n1, n2, n3])
+        cin, dims, ratio, rad = c, [c + 3, n1, n2, n3], 0.5, 0.07
+        x = x0 if c == 3 else (torch.randn(pos.shape[0], c, generator=g) if c else None)
     mod = PN.SAModule(ratio, rad, MLP(dims, batch_norm=True))
     sd = {k: S.synthetic_tensor("sa." + k, tuple(v.shape), 5) for k, v in mod.state_dict().items()}
     mod.load_state_dict(sd)
     mod = mod.to(DEV).eval()
     mod.conv.add_self_loops = self_loops
-    xin = ops.new_rows(x.shape[0], cin, DEV)
-    xin.copy_(x.to(DEV))
+    xin = None
+    if x is not None:
+        xin = ops.new_rows(x.shape[0], cin, DEV)
+        xin.copy_(x.to(DEV))
     seg = Segments(sizes, DEV)
     try:
         saved, PN.FUSED_SA = PN.FUSED_SA, True

@@ -21,6 +21,13 @@ elif which == "direct03":       # a REAL variant (correct results): transform po
     for m in ("WN_PROD_A(X, acc)", "WN_PROD_B(X, acc)", "WN_PROD_A(Y, acc)", "WN_PROD_B(Y, acc)"):
         s = s.replace(m, m.replace("acc", "ACJ"))
     s = s.replace("            if (dz == 2) {                          // this transform position is complete", "            if (dz == 2 && (j == 1 || j == 2)) {    //")
+elif which == "dephase":        # a REAL variant (correct results): the two waves of a SIMD (column groups 0 / 1) convert their halo rows in DIFFERENT groups (2, 4, 7, 10 vs
+    # 3, 5, 8, 11), so that one wave's VALU block runs beside the other's MFMAs instead of beside its VALU block
+    s = s.replace("            if (g == 2) { affine_rows(sn); convert(0, nslo[0]); }\n", "            if (g == 2 + cg_odd) { affine_rows(sn); convert(0, nslo[0]); }\n")
+    for g, j in ((4, 1), (7, 2), (10, 3)):
+        s = s.replace(f"            if (g == {g}) convert({j}, nslo[{j}]);\n", f"            if (g == {g} + cg_odd) convert({j}, nslo[{j}]);\n")
+    s = s.replace("            else if (g == 3 || g == 5 || g == 8 || g == 11) GN_WAIT_VM_LGKM0(2);", "            else if (g != 2 && g != 7 && g != 10) GN_WAIT_VM_LGKM0(2);")
+    s = s.replace("    int sbase = 0;                                  // (4 s) % 5: slot of this slice's j = 0", "    const int cg_odd = cg;\n    int sbase = 0;                                  //")
 elif which == "noconvert":      # no staging conversions inside the loop (slice 0's halo is reused for every slice)
     for g, j in ((2, 0), (4, 1), (7, 2), (10, 3)):
         s = s.replace(f"            if (g == {g}) {{ affine_rows(sn); convert(0, nslo[0]); }}\n", "")
