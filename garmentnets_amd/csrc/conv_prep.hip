@@ -12,7 +12,7 @@
 // 444 -> 544 TFLOP/s-eq for the first layer (tools/dev/sparsity_burn.py).  Every tile still goes through the matrix cores.
 //
 // This file: the per-batch preparation (three small kernels) -- scales and staging affine, row maxima + the K table (fp64), the weight pack
-// in the MFMA-fragment order of unet_split.hip ([sample][Cin/16][27][Cout/32][plane][64 lanes][8 fp16] + four zero steps at the end).
+// in the MFMA-fragment order of unet_split.hip ([sample][Cin/16][27][Cout/32][plane][64 lanes][8 fp16] + eight zero steps at the end).
 #include "common.h"
 
 // per (sample, channel): operand scale s = 2^k with rms(x - c) * s in [1, 2) (a channel's values are bounded by rms sqrt(V): no fp16
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void cprep_pack_wino_kernel(const float *__res
 extern "C" size_t gn_conv_affine_pack_bytes(int B, int Cin, int Cout) {
     if (B < 0 || Cin <= 0 || Cout <= 0 || Cin % 16 || Cout % 32) return 0;
     const size_t step = (size_t)(Cout / 32) * 2 * 1024;                    // bytes per (slice, tap) step
-    return ((size_t)B * (Cin / 16) * 27 + 4) * step;                       // + four zero steps behind the last sample (the kernels' DMA look-ahead)
+    return ((size_t)B * (Cin / 16) * 27 + 8) * step;                       // + eight zero steps behind the last sample (the kernels' DMA look-ahead: the x-strip kernel requests two groups of three steps ahead)
 }
 
 extern "C" size_t gn_conv_affine_pack_wino_bytes(int B, int Cin, int Cout) {
@@ -198,7 +198,7 @@ static int conv_affine_pack_impl(const float *w, int Cin, int Cout, const float 
     float *rowscale = wfac + (size_t)B * Cin;                               // [B][Cout]
     const int nsteps = wino ? 36 : 27;
     const size_t step = (size_t)(Cout / 32) * 2 * 1024, per_sample = (size_t)(Cin / 16) * nsteps * step;
-    GN_HIP(hipMemsetAsync((char *)pack + (size_t)B * per_sample, 0, (wino ? CPREP_WINO_PAD : 4) * step, st), "gn_conv_affine_pack");
+    GN_HIP(hipMemsetAsync((char *)pack + (size_t)B * per_sample, 0, (wino ? CPREP_WINO_PAD : 8) * step, st), "gn_conv_affine_pack");
     hipLaunchKernelGGL(cprep_scales_kernel, dim3((unsigned)gn_cdiv((int64_t)B * Cin, 256)), dim3(256), 0, st, sum, sumsq, (double)V, a, d, coff, B * Cin,
                        stage_a, stage_d, wfac, mconst);
     if (wino) hipLaunchKernelGGL(cprep_rows_kernel<true>, dim3((unsigned)Cout, (unsigned)B), dim3(64), 0, st, w, wfac, mconst, Cin, Cout, rowscale, out_scale, kbias);

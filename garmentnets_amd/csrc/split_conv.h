@@ -25,7 +25,7 @@ struct SplitArgs {
     const float *src1;
     const float *a;
     const float *d;
-    const uint4 *wp;   // [slice][tap][Cout/32][P][lane 64] x 16 B (8 bf16: channels 8h..8h+7 of cout 32*blk + r, lane = 32h + r), + four zero pad steps
+    const uint4 *wp;   // [slice][tap][Cout/32][P][lane 64] x 16 B (8 bf16: channels 8h..8h+7 of cout 32*blk + r, lane = 32h + r), + eight zero pad steps
     float *out;
     double *osum;
     double *osq;

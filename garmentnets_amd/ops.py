@@ -315,8 +315,8 @@ class SplitPack:
 
 def pack_conv_weight_split(w, mode):
     """(Cout, Cin, 3,3,3) fp32 -> exact plane decomposition (w = w1 + w2 [+ w3], residual chain) in MFMA-fragment order
-    [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by four zero
-    (slice, tap) steps: the kernel's fragment DMA runs up to four steps ahead.  mode SPLIT_BF16X2/3: bf16 planes;
+    [Cin/16][27][Cout/32][planes][h 2][r 32][8] (lane 32h+r holds channels 8h..8h+7 of cout 32*blk+r), followed by eight zero
+    (slice, tap) steps: the kernels' fragment DMA runs up to two groups of three steps ahead of the last one.  mode SPLIT_BF16X2/3: bf16 planes;
     SPLIT_F16X2: two fp16 planes of w * 2^k(cout), k chosen PER OUTPUT CHANNEL so that the row maximum max|w[cout]| * 2^k is in [1, 2)
     (out_scale[cout] = 2^-k undoes it exactly): every weight within 2^3 of its row's largest keeps a normal second plane (residual
     <= 2^-22 |w|), smaller ones are carried to 2^-25 of the row maximum -- always far below the row's own dot-product magnitude,
@@ -340,7 +340,7 @@ def pack_conv_weight_split(w, mode):
         r = r - p.float()
     pk = torch.stack(out, dim=3).contiguous()                                                            # [S][tap][blk][planes][h][r][8]
     pk = pk.reshape(cin // 16 * 27, -1)
-    pk = torch.cat([pk, torch.zeros_like(pk[:4])], dim=0)
+    pk = torch.cat([pk, torch.zeros_like(pk[:1]).repeat(8, 1)], dim=0)
     return SplitPack(pk.contiguous().view(torch.int16), mode, (1.0 / scale).contiguous().to(w.device))
 
 

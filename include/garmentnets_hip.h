@@ -191,7 +191,7 @@ int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C1, const fl
  *                    2^3 of their scale (below: absolute, 2^-25 of the scale).  Scales: one power of two per OUTPUT CHANNEL for the
  *                    weights (row maximum in [1, 2)) and one per SAMPLE for the activations (gn_groupnorm_affine act_inv_scale)
  *   GN_SPLIT_BF16X2: 2 bf16 planes, 3 partial products, 2^-16 relative (fast preview quality)
- * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + four zero steps
+ * wp_planes: weight pack in MFMA-fragment order [Cin/16][27 taps][Cout/32][planes][64 lanes] x 16 B + eight zero steps
  * (garmentnets_amd.ops.pack_conv_weight_split); out_scale [Cout]: the exact powers of two that undo the pack's per-output-channel
  * weight scales (all 1 for bf16); act_inv_scale: NULL or [B] from gn_groupnorm_affine. */
 #define GN_SPLIT_BF16X2 2
