@@ -540,9 +540,13 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSpl
                 if (qd & 1) {
                     ds_split2(v0, v1, h1[0][g2].z, h1[1][g2].z);
                     ds_split2(v2, v3, h1[0][g2].w, h1[1][g2].w);
+                    // (the layer-2 operand planes are pinned into AGPRs where they are produced: MFMA B operands may be AGPRs, and without the pin hipcc
+                    //  spills 34 values around the MFMA stream; with it: no scratch, 402 -> 432 TF-eq, same digests)
+                    asm volatile("" : "+a"(h1[0][g2].z), "+a"(h1[1][g2].z), "+a"(h1[0][g2].w), "+a"(h1[1][g2].w));
                 } else {
                     ds_split2(v0, v1, h1[0][g2].x, h1[1][g2].x);
                     ds_split2(v2, v3, h1[0][g2].y, h1[1][g2].y);
+                    asm volatile("" : "+a"(h1[0][g2].x), "+a"(h1[1][g2].x), "+a"(h1[0][g2].y), "+a"(h1[1][g2].y));
                 }
             }
         };
