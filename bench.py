@@ -769,12 +769,23 @@ def main():
         sampler = HwmonSampler(dev_index) if (hw_name and rank == 0) else None
         if sampler is not None:
             sampler.__enter__()
+        if os.environ.get("GARMENTNETS_BENCH_STALL_TRACE"):      # debugging aid: where is the host when a timed pass stalls (stack of every thread, every 100 ms)
+            import faulthandler
+            faulthandler.dump_traceback_later(0.1, repeat=True)
         t0 = time.perf_counter()
         res = run_steps(fn, steps)
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if os.environ.get("GARMENTNETS_BENCH_STALL_TRACE"):
+            faulthandler.cancel_dump_traceback_later()
+            ms_ = torch.cuda.memory_stats()
+            print(f"[stall-trace] pass {hw_name}: steps returned after {1e3 * (t1 - t0):.1f} ms, synchronised after {1e3 * dt:.1f} ms; allocator: "
+                  f"retries {ms_.get('num_alloc_retries')} device_alloc {ms_.get('num_device_alloc')} device_free {ms_.get('num_device_free')} "
+                  f"reserved {ms_.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB (peak {ms_.get('reserved_bytes.all.peak', 0) / 2**30:.1f}) "
+                  f"allocated peak {ms_.get('allocated_bytes.all.peak', 0) / 2**30:.1f} GiB", file=sys.stderr, flush=True)
         if sampler is not None:
             sampler.__exit__(None, None, None)
             hw_passes[hw_name] = sampler.summary()
@@ -793,8 +804,11 @@ def main():
         pmc_child(args, model, data, step)
         return
     pipelined[0] = args.workload == "full" and args.pipeline_depth == 2 and not auto_level[0]
-    dt, res, groups = timed(step, args.steps, max(2, args.warmup - 1) if pipelined[0] else max(0, args.warmup - (1 if args.workload == "full" else 0)),
-                            hw_name="headline")
+    # warm-up: the W steps asked for, all of them HERE -- the level probe above is an extra untimed step, not one of the W.  (It used to count as
+    # one: at W = 1 the timed region then began on an allocator that had seen ONE step, and whether its first timed step found every block
+    # cached or paid a 17 GB hipMalloc -- ~0.5 s on these boxes -- came down to which cross-stream frees of the probe had been polled as
+    # complete: the same build measured 59 or 143 garments/s depending on it, profiles/r05_ab_experiments.txt section 17.)
+    dt, res, groups = timed(step, args.steps, max(2, args.warmup) if pipelined[0] else max(1, args.warmup), hw_name="headline")
     verts_total = None
     checksums = []                                   # per local garment: fp64 sum of its WNF volume (full) / logits (pointnet2), last timed step
     probe = None                                     # slot 0 of the timed result, kept for the oracle check of the cpu_baseline leg

@@ -55,6 +55,7 @@ struct SplitArgs {
     int kreach;               // 1: the layer fed by the scattered volume (27 classes); 2: the layer behind it (125 classes: distance 0 / 1 from
                               // a face or further, per axis); class index per axis c = z < r ? z : (z >= D - r ? 2r - (D-1-z) : r), kconst
                               // [B][(2r+1)^3][Cout] ordered (cz * n + cy) * n + cx
+    int chain;                // conv3d_split_wino_kernel: tiles per workgroup (set by gn_launch_conv3d_wino)
 };
 
 // Work item of this workgroup: sample b, tile (index inside the sample at the kernel's tile granularity), column block cb.

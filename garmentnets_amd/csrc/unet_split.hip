@@ -1009,7 +1009,7 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
     p.C0 = C0; p.C1 = C1; p.B = B; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu; p.out_scale = out_scale; p.act_inv = act_inv_scale;
     p.active_list = nullptr; p.active_count = nullptr; p.kconst = kconst; p.kreach = kreach; p.partial = partial;
-    p.kbias = kbias; p.wp_bstride = wp_bstride; p.osc_bstride = osc_bstride;
+    p.kbias = kbias; p.wp_bstride = wp_bstride; p.osc_bstride = osc_bstride; p.chain = 1;
     GN_REQUIRE(!partial || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "gn_conv3d_gcr_split: a polyphase partial needs even dims");
     const int tz = (int)gn_cdiv(D, SP_TZ);
     p.tiles_y = (int)gn_cdiv(H, SP_TY);

@@ -669,6 +669,57 @@ def test_conv3d_winograd_occupancy_aware_launch_and_shape_contract():
     assert not ops.wino_supported(32, 64, (8, 8, 8)) and not ops.wino_supported(272, 128, (8, 8, 8)) and ops.wino_supported(256, 256, (4, 8, 8))
 
 
+def test_conv3d_winograd_chain_length_does_not_change_a_bit(monkeypatch):
+    """the Winograd kernel's workgroups walk CHAINS of tiles (csrc/unet_wino.hip: a tile's last slice stages the next tile's first; the
+    epilogue statistics leave once per chain): outputs are bit-identical for every chain length -- 1 (one tile per workgroup), 2 / 3 (chains
+    that cross from one sample into the next: the drain-and-restart path; Cout = 256: two column blocks interleaved in the item order), 16 --
+    for the literal form, the per-sample packs and the occupancy-aware (active-list) launch; the statistics agree to fp64 rounding (they are
+    merged by fp64 atomics in whatever order the hardware schedules them, as in every launch of these kernels)."""
+    from garmentnets_amd.components.unet3d import SingleConv
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for (B, D, H, W, C, Cout) in ((3, 16, 32, 32, 32, 128), (2, 8, 24, 40, 64, 256)):
+        x = torch.randn(B, D, H, W, C, generator=g).to(DEV)
+        w = torch.randn(Cout, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        st = ops.channel_stats(x)
+        a, d, inv = ops.groupnorm_affine(st, None, 8, 1e-5, gamma, beta, with_act_scale=True)
+        a0, d0 = ops.groupnorm_affine(st, None, 8, 1e-5, gamma, beta)
+        cases.append((x, a, d, inv, ops.pack_conv_weight_split_wino(w).to(DEV), ops.conv_affine_pack(w.to(DEV).contiguous(), a0, d0, st, wino=True), Cout))
+    # occupancy-aware: a scattered 32^3 volume through SingleConv (active-tile list + class constants)
+    Bs, G, C = 4, 32, 32
+    conv = SingleConv(C, 128).to(DEV)
+    conv.load_state_dict({k: S.synthetic_tensor("wc." + k, tuple(v.shape), 4).to(DEV) for k, v in conv.state_dict().items()})
+    xs = torch.zeros(Bs, G, G, G, C)
+    idx = torch.randint(0, G, (Bs, 60, 3), generator=g)
+    for b in range(Bs):
+        xs[b, idx[b, :, 0], idx[b, :, 1], idx[b, :, 2]] = torch.randn(60, C, generator=g).abs() * 2.0
+    flat = torch.cat([((b * G + idx[b, :, 0]) * G + idx[b, :, 1]) * G + idx[b, :, 2] for b in range(Bs)]).to(torch.int32).to(DEV)
+    xs = xs.to(DEV)
+    ar = AR.DEFAULT.replace(conv_mode=AR.SPLIT_F16X2, affine_in_weights=True, winograd=True, sparse_first_conv=True)
+
+    def run_all():
+        out = []
+        for x, a, d, inv, pk, prep, Cout in cases:
+            out.append(ops.conv3d_gcr_split_wino(x, a, d, pk, Cout, act_inv=inv, with_stats=True))
+            out.append(ops.conv3d_gcr_split_persample(x, prep, with_stats=True))
+        out.append(conv.run(xs, None, sparse=dict(flat=flat, reach=1), arith=ar, with_stats=True))
+        assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino_kernel<true>"
+        return out
+
+    monkeypatch.setenv("GARMENTNETS_WINO_CHAIN", "1")
+    ref = run_all()
+    for chain in ("2", "3", "16"):
+        monkeypatch.setenv("GARMENTNETS_WINO_CHAIN", chain)
+        for (y0, st0), (y1, st1) in zip(ref, run_all()):
+            assert torch.equal(y0, y1), f"chain {chain}"
+            for s0_, s1_ in zip(st0[:2], st1[:2]):
+                assert float((s0_ - s1_).abs().max()) <= 1e-12 * max(1.0, float(s0_.abs().max())), f"chain {chain}"
+    monkeypatch.delenv("GARMENTNETS_WINO_CHAIN")
+    for (y0, _), (y1, _) in zip(ref, run_all()):                      # the launcher's own choice
+        assert torch.equal(y0, y1)
+
+
 CONV_ORDERS = ("gcr", "cr", "crg", "cl", "ce", "bcr", "cbr", "cgr")
 
 
