@@ -297,11 +297,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
                 // (g+1, 2): the youngest two may stay in flight; at g == 1 also the NIT row loads issued at the very end of group 0.  Groups 3, 5, 8,
                 // 11 follow a conversion group: their barrier also publishes this wave's halo stores (lgkmcnt(0); elsewhere the only LDS operations
                 // in flight are the fragment reads issued a few instructions ago, which hipcc waits for right before the MFMA that consumes them).
-                // (Behind a tile boundary the previous tile's 64 output stores per lane sit in the queue in front of (1, 1): group 0 waits them out.)
+                // Group 0 of a tile's FIRST slice has had its hand-over already: behind the prologue's barriers (a run's first tile), or at the
+                // barrier in front of the previous tile's epilogue (below) -- here it would wait for that epilogue's stores to be acknowledged
                 if (g == 1) GN_WAIT_VM_ONLY(2 + NIT);
                 else if (g == 3 || g == 5 || g == 8 || g == 11) GN_WAIT_VM_LGKM0(2);
-                else GN_WAIT_VM_ONLY(2);
-                __builtin_amdgcn_s_barrier();
+                else if (g > 0 || s > 0) GN_WAIT_VM_ONLY(2);
+                if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();
                 WN_READ(Y, slo[j], dz * WL::HY + 1, (g % RING) * GB + STEPB);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g == 10) bgs += wrap;
@@ -370,6 +371,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
             }
             sbase = nbase;
         }
+        // the next tile's group-0 hand-over, in front of the epilogue: steps 1, 2 of its group 0 and step 0 of its group 1 have landed (the
+        // youngest two pieces stay in flight), every wave is through with this tile's last ring slot
+        GN_WAIT_VM_ONLY(2);
+        __builtin_amdgcn_s_barrier();
 
         // ---- epilogue of this tile.  D fragment element q of lane (h, r): pair row i = (q & 3) + 8 (q >> 2) + 4 h = (y = 2 (q >> 2) + h, pair = q & 3),
         // channel r.  (Everything the epilogue derives from the tile / lane coordinates -- output / bias-table addresses, scale loads -- is computed
@@ -390,7 +395,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
             const bool classes = p.kbias && !interior;
             const int mz = sp_axis_mask(gz, p.D);
             // stores: wave-uniform 64-bit base of output row pair (q >> 2) in SGPRs + a 32-bit lane offset per (e, u, q & 3): no 64-bit VALU
-            // arithmetic, nothing for hipcc to hoist
+            // arithmetic, nothing for hipcc to hoist.  Non-temporal: the layer's output is read once, by the next launch, and is far larger than
+            // L2 + MALL; with the hint the 64 stores per lane are acknowledged sooner (they sit in the in-order VM queue in front of the next
+            // tile's weight pieces): 2 - 3 % of the launch
             const float *const orow = p.out + ((((int64_t)be * p.D + gz) * p.H + y0e) * p.W + x0e) * p.Cout + n0;
             const int64_t rs2 = 2 * (int64_t)p.W * p.Cout;
 #pragma unroll
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
                         if (p.kbias) v = __fadd_rn(v, kv[u][q]);
                         if (p.relu) v = gn_relu(v);
                         const float *ob = orow + (q >> 2) * rs2;       // (uniform)
-                        asm volatile("global_store_dword %0, %1, %2" ::"v"(vo[q & 3]), "v"(v), "s"(ob) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(vo[q & 3]), "v"(v), "s"(ob) : "memory");
                         ssum[u] += (double)v;
                         ssq[u] += (double)v * (double)v;
                     }
