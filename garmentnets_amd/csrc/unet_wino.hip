@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
             const bool last = s + 1 == nslices;
             // what this slice stages: the tile's next slice -- or, behind the last one, slice 0 of the next tile (not `cont`: slots nobody
             // reads any more and the pack's zero pad steps; no branch inside the MFMA stream)
-            const int sn = last ? 0 : s + 1;
+            const int sn = last ? (cont ? 0 : s) : s + 1;         // (nothing follows: this slice's own rows again -- they sit in L2)
             if (last && cont) set_rows(z0n, y0n, x0n);
             const int64_t wrap = last && cont ? -(int64_t)nslices * 36 * bstep : 0;       // the weight cursor returns to the pack's start at group 10
             const int nbase = sbase == 0 ? 4 : sbase - 1;                          // (sbase + 4) % 5
