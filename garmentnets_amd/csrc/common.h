@@ -70,4 +70,19 @@ __device__ __forceinline__ void gn_glds16(const void *g, unsigned lds_addr) {
 // (e.g. an activation beyond the fp16 range in the split-operand kernels) into a silently wrong finite result.
 __device__ __forceinline__ float gn_relu(float v) { return v < 0.f ? 0.f : v; }
 
+// Exact residual of an fp32 value r against one half of a packed fp16 pair h2 in ONE instruction: v_fma_mix_f32 reads the fp16 half in place,
+// fma(f32(h), -1, r) = r - f32(h) with one rounding -- of a value that IS representable when h = fp16_rn(r) or any fp16 within the split's range (the
+// difference has at most 13 significant bits), so the result is bit-identical to v_cvt_f32_f16 + v_sub_f32 (hipcc's selection for the C
+// expression: two instructions per value; the plane split is the largest VALU item of every f16x2 kernel).  Not volatile: schedulable, removable.
+__device__ __forceinline__ float gn_resid_lo(unsigned h2, float r) {
+    float o;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h2), "v"(r));
+    return o;
+}
+__device__ __forceinline__ float gn_resid_hi(unsigned h2, float r) {
+    float o;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h2), "v"(r));
+    return o;
+}
+
 __device__ __forceinline__ int gn_lane() { return threadIdx.x & 63; }

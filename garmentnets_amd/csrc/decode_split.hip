@@ -109,10 +109,9 @@ __device__ __forceinline__ void lat_issue(const float *vol, unsigned off, int ha
 __device__ __forceinline__ void ds_split2(float a, float b, unsigned &p1, unsigned &p2) {
     const f32x2q v = {a, b};
     const h16x2 x1 = __builtin_convertvector(v, h16x2);
-    const f32x2q back = __builtin_convertvector(x1, f32x2q);
-    const f32x2q res = {__fsub_rn(a, back.x), __fsub_rn(b, back.y)};
-    const h16x2 x2 = __builtin_convertvector(res, h16x2);
     p1 = __builtin_bit_cast(unsigned, x1);
+    const f32x2q res = {gn_resid_lo(p1, a), gn_resid_hi(p1, b)};      // (exact residuals, one v_fma_mix_f32 each: common.h)
+    const h16x2 x2 = __builtin_convertvector(res, h16x2);
     p2 = __builtin_bit_cast(unsigned, x2);
 }
 

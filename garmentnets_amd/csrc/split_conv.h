@@ -102,9 +102,8 @@ __device__ __forceinline__ void split4(float r0, float r1, float r2, float r3, u
             const f16x2v blo = __builtin_convertvector(lo, f16x2v), bhi = __builtin_convertvector(hi, f16x2v);
             out[i].x = __builtin_bit_cast(unsigned, blo);
             out[i].y = __builtin_bit_cast(unsigned, bhi);
-            if (i + 1 < P) {
-                const f32x2v flo = __builtin_convertvector(blo, f32x2v), fhi = __builtin_convertvector(bhi, f32x2v);
-                r0 = __fsub_rn(r0, flo.x); r1 = __fsub_rn(r1, flo.y); r2 = __fsub_rn(r2, fhi.x); r3 = __fsub_rn(r3, fhi.y);
+            if (i + 1 < P) {                       // (exact residuals, one v_fma_mix_f32 each: common.h)
+                r0 = gn_resid_lo(out[i].x, r0); r1 = gn_resid_hi(out[i].x, r1); r2 = gn_resid_lo(out[i].y, r2); r3 = gn_resid_hi(out[i].y, r3);
             }
             continue;
         }

@@ -42,8 +42,7 @@ __device__ __forceinline__ void up_split4(float r0, float r1, float r2, float r3
         const f16x2u blo = __builtin_convertvector(lo, f16x2u), bhi = __builtin_convertvector(hi, f16x2u);
         out[0].x = __builtin_bit_cast(unsigned, blo);
         out[0].y = __builtin_bit_cast(unsigned, bhi);
-        const f32x2u flo = __builtin_convertvector(blo, f32x2u), fhi = __builtin_convertvector(bhi, f32x2u);
-        const f32x2u rlo = {__fsub_rn(r0, flo.x), __fsub_rn(r1, flo.y)}, rhi = {__fsub_rn(r2, fhi.x), __fsub_rn(r3, fhi.y)};
+        const f32x2u rlo = {gn_resid_lo(out[0].x, r0), gn_resid_hi(out[0].x, r1)}, rhi = {gn_resid_lo(out[0].y, r2), gn_resid_hi(out[0].y, r3)};   // (common.h)
         out[1].x = __builtin_bit_cast(unsigned, __builtin_convertvector(rlo, f16x2u));
         out[1].y = __builtin_bit_cast(unsigned, __builtin_convertvector(rhi, f16x2u));
     } else {
