@@ -68,7 +68,10 @@ __device__ __forceinline__ void gn_glds16(const void *g, unsigned lds_addr) {
 
 // ReLU with torch's NaN behaviour (relu(NaN) = NaN).  fmaxf(v, 0) would return 0 for a NaN and turn an upstream overflow
 // (e.g. an activation beyond the fp16 range in the split-operand kernels) into a silently wrong finite result.
-__device__ __forceinline__ float gn_relu(float v) { return v < 0.f ? 0.f : v; }
+// IEEE 754-2019 maximum(v, 0) -- NaN-propagating -- is ONE gfx950 instruction (v_maximum3_f32 v, v, 0, 0); the C form `v < 0 ? 0 : v`
+// compiled to v_cmp_ngt_f32 + 2 hazard wait states on vcc + v_cndmask_b32 per value (the largest VALU item of the decoder MLPs'
+// layer hand-over).  Same values; the only bit that can differ is the sign of a zero (maximum(-0, +0) = +0, the C form kept -0).
+__device__ __forceinline__ float gn_relu(float v) { return __builtin_elementwise_maximum(v, 0.f); }
 
 // Exact residual of an fp32 value r against one half of a packed fp16 pair h2 in ONE instruction: v_fma_mix_f32 reads the fp16 half in place,
 // fma(f32(h), -1, r) = r - f32(h) with one rounding -- of a value that IS representable when h = fp16_rn(r) or any fp16 within the split's range (the

@@ -115,6 +115,13 @@ __device__ __forceinline__ void ds_split2(float a, float b, unsigned &p1, unsign
     p2 = __builtin_bit_cast(unsigned, x2);
 }
 
+// bias + ReLU of an accumulator register quad: the adds as two v_pk_add_f32 (the same IEEE additions, half the issue slots), the ReLU as one v_maximum3_f32 each (gn_relu)
+__device__ __forceinline__ void ds_bias_relu4(float a0, float a1, float a2, float a3, const float4 &bv, float &v0, float &v1, float &v2, float &v3) {
+    const f32x2q s01 = (f32x2q){a0, a1} + (f32x2q){bv.x, bv.y};
+    const f32x2q s23 = (f32x2q){a2, a3} + (f32x2q){bv.z, bv.w};
+    v0 = gn_relu(s01.x); v1 = gn_relu(s01.y); v2 = gn_relu(s23.x); v3 = gn_relu(s23.y);
+}
+
 __device__ __forceinline__ f32x16q ds_mfma(const uint4 &a, const uint4 &b, const f32x16q &c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
@@ -131,6 +138,18 @@ __device__ __forceinline__ void ds_glds16(const void *g, unsigned lds_addr) {  /
 // the same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset: no 64-bit VALU address arithmetic per piece
 __device__ __forceinline__ void ds_glds16_s(const void *sbase, unsigned voff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+// a wave's four 1-KB pieces of one stage in one statement: ONE scalar base and ONE m0 value, the pieces told apart by the instruction's immediate
+// offset -- which the hardware adds to the global AND to the LDS address (LLVM's llvm.amdgcn.global.load.lds: "imm offset (applied to both global
+// and LDS address)"), and both step by 1024 from piece to piece.  Four statements with four bases made hipcc keep 72 address pairs in SGPRs across
+// the tile loop and spill them into VGPR lanes: 79 - 130 v_readlane_b32 per tile in the VALU stream of a VALU-issue-bound kernel.
+__device__ __forceinline__ void ds_glds16x4_s(const void *sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); expcnt left at 7 (no wait)
@@ -181,8 +200,7 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     static_assert(!LAT || SB_ZERO, "the 3-stage ring is indexed with compile-time slots");
 #define DS_SB (SB_ZERO ? 0 : sb)
 #define DS_ISSUE(STAGE, SLOT)                                                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                              \
-        ds_glds16_s(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES + c * 1024, lane16, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
+    ds_glds16x4_s(wsrc + (size_t)(STAGE) * DS_STAGE_BYTES, lane16, lds_base + (SLOT) * DS_STAGE_BYTES + (wave * 4) * 1024);
     DS_ISSUE(0, 0) DS_ISSUE(1, 1) DS_ISSUE(2, 2)
     if (!LAT) { DS_ISSUE(3, 3) }
 
@@ -252,10 +270,8 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
                 if (P < 4) {
                     const int nb = 2 * P + blk;
                     const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
-                    const float v0 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 0], bv.x));
-                    const float v1 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 1], bv.y));
-                    const float v2 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 2], bv.z));
-                    const float v3 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 3], bv.w));
+                    float v0, v1, v2, v3;
+                    ds_bias_relu4(acc[set][blk][4 * qd + 0], acc[set][blk][4 * qd + 1], acc[set][blk][4 * qd + 2], acc[set][blk][4 * qd + 3], bv, v0, v1, v2, v3);
                     // registers 0-7 -> k-group 2nb, 8-15 -> k-group 2nb+1 of layer 2; a register quad fills half a fragment
                     const int g2 = 2 * nb + (qd >> 1);
                     if (qd & 1) {
@@ -269,10 +285,8 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
                     const int nb = 2 * (P - 4) + blk;
                     const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
                     const float4 bv = *reinterpret_cast<const float4 *>(tb);
-                    const float v0 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 0], bv.x));
-                    const float v1 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 1], bv.y));
-                    const float v2 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 2], bv.z));
-                    const float v3 = gn_relu(__fadd_rn(acc[set][blk][4 * qd + 3], bv.w));
+                    float v0, v1, v2, v3;
+                    ds_bias_relu4(acc[set][blk][4 * qd + 0], acc[set][blk][4 * qd + 1], acc[set][blk][4 * qd + 2], acc[set][blk][4 * qd + 3], bv, v0, v1, v2, v3);
 #pragma unroll
                     for (int o = 0; o < OUTC; ++o) {
                         const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);
@@ -469,9 +483,7 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSpl
     const unsigned lane16 = lane * 16;
     // stage `st` (0 .. NSTAGE-1, wrapping into the next tile) -> ring slot `slot`
     auto issue = [&](int st, int slot) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            ds_glds16_s(wsrc + (size_t)st * DS_STAGE_BYTES + c * 1024, lane16, lds_base + slot * DS_STAGE_BYTES + (wave * 4 + c) * 1024);
+        ds_glds16x4_s(wsrc + (size_t)st * DS_STAGE_BYTES, lane16, lds_base + slot * DS_STAGE_BYTES + (wave * 4) * 1024);
     };
     issue(0, 0); issue(1, 1); issue(2, 2); issue(3, 3);
 
@@ -533,8 +545,8 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSpl
             for (int blk = 0; blk < 2; ++blk) {
                 const int nb = 2 * P + blk;
                 const float4 bv = *reinterpret_cast<const float4 *>(tab + (nb * 2 + h) * 16 + 4 * qd);
-                const float v0 = gn_relu(__fadd_rn(ac[blk][4 * qd + 0], bv.x)), v1 = gn_relu(__fadd_rn(ac[blk][4 * qd + 1], bv.y));
-                const float v2 = gn_relu(__fadd_rn(ac[blk][4 * qd + 2], bv.z)), v3 = gn_relu(__fadd_rn(ac[blk][4 * qd + 3], bv.w));
+                float v0, v1, v2, v3;
+                ds_bias_relu4(ac[blk][4 * qd + 0], ac[blk][4 * qd + 1], ac[blk][4 * qd + 2], ac[blk][4 * qd + 3], bv, v0, v1, v2, v3);
                 const int g2 = 2 * nb + (qd >> 1);
                 if (qd & 1) {
                     ds_split2(v0, v1, h1[0][g2].z, h1[1][g2].z);
@@ -556,8 +568,8 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSpl
                 const int nb = 2 * P2 + blk;
                 const float *tb = tab + TAB1 + ((nb * 2 + h) * (1 + OUTC)) * 16 + 4 * qd;
                 const float4 bv = *reinterpret_cast<const float4 *>(tb);
-                const float v0 = gn_relu(__fadd_rn(ac[blk][4 * qd + 0], bv.x)), v1 = gn_relu(__fadd_rn(ac[blk][4 * qd + 1], bv.y));
-                const float v2 = gn_relu(__fadd_rn(ac[blk][4 * qd + 2], bv.z)), v3 = gn_relu(__fadd_rn(ac[blk][4 * qd + 3], bv.w));
+                float v0, v1, v2, v3;
+                ds_bias_relu4(ac[blk][4 * qd + 0], ac[blk][4 * qd + 1], ac[blk][4 * qd + 2], ac[blk][4 * qd + 3], bv, v0, v1, v2, v3);
 #pragma unroll
                 for (int o = 0; o < OUTC; ++o) {
                     const float4 wv = *reinterpret_cast<const float4 *>(tb + (1 + o) * 16);

@@ -107,6 +107,14 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // cross-wave exchange, ~60 instructions per wave) is paid once per wave: 4 waves per SIMD spent as long in it as in the update.
 // The update itself runs on point PAIRS in packed fp32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, half the issue slots).
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
+// running minimum in ONE instruction: fminf() compiles to two canonicalising v_max_f32 + v_min_f32 under the IEEE mode bit (3 instructions per point in a
+// loop of ~8); v_min_f32 itself returns the non-NaN operand, i.e. what `if (d < dist) dist = d` leaves (oracle/gn_oracle.c gno_fps)
+__device__ __forceinline__ float fps_min(float a, float b) {
+    float o;
+    asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
 template <int PPT, bool LDS_POS, int THREADS>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
                                                       const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ start_idx,
@@ -132,10 +140,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         if (i < n) {
             px[j] = gp[3 * i]; py[j] = gp[3 * i + 1]; pz[j] = gp[3 * i + 2];
             if (LDS_POS) { lx[i] = px[j]; ly[i] = py[j]; lz[i] = pz[j]; }
+            dd[j] = 3.0e38f;
         } else {
+            // a slot past the example's last point: finite coordinates and a running distance of -1 -- min(-1, d) stays -1 and -1 never beats
+            // the arg-max's start value, so the update needs no per-slot guard (the guards cut the unrolled update into 24 exec-masked blocks)
             px[j] = py[j] = pz[j] = 0.f;
+            dd[j] = -1.f;
         }
-        dd[j] = 3.0e38f;
     }
     if (LDS_POS) __syncthreads();
     int last = start_idx ? start_idx[b] : 0;   // torch_cluster random_start: the host draws the start; default first point
@@ -146,13 +157,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         if (LDS_POS) { qx = lx[last]; qy = ly[last]; qz = lz[last]; }
         else { qx = gp[3 * last]; qy = gp[3 * last + 1]; qz = gp[3 * last + 2]; }
         float bv = -1.f;
-        int bi = INT_MAX;
+        int bj = 0;                                // slot of the lane's best point (point index tid + bj * THREADS)
         if (PPT == 1) {
-            if (tid < n) {
-                float d = fminf(dd[0], gn_sqdist3(px[0], py[0], pz[0], qx, qy, qz));
-                dd[0] = d;
-                if (d > bv) { bv = d; bi = tid; }
-            }
+            const float d = fps_min(dd[0], gn_sqdist3(px[0], py[0], pz[0], qx, qy, qz));
+            dd[0] = d;
+            bv = d > bv ? d : bv;
         } else {
             const fps_f2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
@@ -162,17 +171,19 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
                 const fps_f2 d2 = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int i = tid + (j + u) * THREADS;
-                    if (i < n) {
-                        const float d = fminf(dd[j + u], u ? d2.y : d2.x);
-                        dd[j + u] = d;
-                        if (d > bv) { bv = d; bi = i; }  // ascending i: ties keep the lowest index
-                    }
+                    const float d = fps_min(dd[j + u], u ? d2.y : d2.x);
+                    dd[j + u] = d;
+                    if (d > bv) { bv = d; bj = j + u; }  // ascending slot = ascending point index: ties keep the lowest index
                 }
             }
         }
+        const int bi = bv >= 0.f ? tid + bj * THREADS : INT_MAX;   // (a lane whose slots are all past the end holds -1)
         const float wv = wave_max_f(bv);
-        const int wi = wave_min_i(bv == wv ? bi : INT_MAX);
+        // the lanes that hold the wave's maximum: one lane in all but exact ties -> its index is read directly; ties take the DPP min
+        const unsigned long long hit = __ballot(bv == wv);
+        int wi;
+        if (__builtin_popcountll(hit) == 1) wi = __builtin_amdgcn_readlane(bi, __builtin_ctzll(hit));
+        else wi = wave_min_i(bv == wv ? bi : INT_MAX);
         const int par = (k & 1) * WAVES;
         if (lane == 0) { pv[par + wave] = wv; pi[par + wave] = wi; }
         __syncthreads();
