@@ -90,6 +90,23 @@ __device__ __forceinline__ int row_min_i(int v) {
     v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
     return v;
 }
+// the same over N <= 16 values replicated with period N along the row: log2(N) steps
+template <int N>
+__device__ __forceinline__ float part_max_f(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_QUAD_XOR1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<DPP_QUAD_XOR2>(__float_as_int(v))));
+    if (N > 4) v = fmaxf(v, __int_as_float(dpp_i<DPP_ROW_HALF_MIRROR>(__float_as_int(v))));
+    if (N > 8) v = fmaxf(v, __int_as_float(dpp_i<DPP_ROW_MIRROR>(__float_as_int(v))));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ int part_min_i(int v) {
+    v = min(v, dpp_i<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_i<DPP_QUAD_XOR2>(v));
+    if (N > 4) v = min(v, dpp_i<DPP_ROW_HALF_MIRROR>(v));
+    if (N > 8) v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_max_f(float v) {
     v = row_max_f(v);
     const int iv = __float_as_int(v);
@@ -190,8 +207,8 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         // lanes 0..WAVES-1 (replicated over the 16-lane DPP row) of every wave reduce the partials
         float fv = pv[par + (lane & (WAVES - 1))];
         int fi = pi[par + (lane & (WAVES - 1))];
-        const float gv = row_max_f(fv);
-        fi = row_min_i(fv == gv ? fi : INT_MAX);
+        const float gv = part_max_f<WAVES>(fv);
+        fi = part_min_i<WAVES>(fv == gv ? fi : INT_MAX);
         last = __builtin_amdgcn_readfirstlane(fi);
         if (tid == 0) out_idx[o0 + k] = s + last;
     }
@@ -204,28 +221,34 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
     const int n = max_points_per_example;
     GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
     const bool lds_pos = n <= 8192;
-    // clouds up to 6144 points: 512 threads with packed-fp32 pair updates (2.73 vs 3.01 ms at n = 6000 with 1024; 256 threads: slower)
-    const bool small = n <= 12 * 512;
-    const int threads = small ? 512 : FPS_THREADS;
+    // ONE wave per SIMD for as long as its points fit the registers (24 per lane): the min-update costs the same issue slots however it is spread, the
+    // arg-max reduction and the exchange are paid per wave (n = 6000: 256 threads 2.13 ms, 512 threads 2.26 ms, 1024 threads 3.0 ms)
+#ifndef FPS_MID_THREADS
+#define FPS_MID_THREADS 512
+#endif
+    const int threads = n <= 24 * 256 ? 256 : (n <= 24 * FPS_MID_THREADS ? FPS_MID_THREADS : FPS_THREADS);
     size_t sh = sizeof(float) * 4 * (threads / 64) + (lds_pos ? sizeof(float) * 3 * (size_t)n : 0);
-    int ppt = (int)gn_cdiv(n, threads);
+    const int ppt = (int)gn_cdiv(n, threads);
 #define FPS_LAUNCH(P, L, T)                                                                                     \
     do {                                                                                                        \
         GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
         hipLaunchKernelGGL((fps_kernel<P, L, T>), dim3(B), dim3(T), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
     } while (0)
-    if (small) {
-        if (ppt <= 2) FPS_LAUNCH(2, true, 512);
-        else if (ppt <= 4) FPS_LAUNCH(4, true, 512);
-        else if (ppt <= 6) FPS_LAUNCH(6, true, 512);
-        else if (ppt <= 8) FPS_LAUNCH(8, true, 512);
-        else FPS_LAUNCH(12, true, 512);
-    } else if (ppt <= 1) FPS_LAUNCH(1, true, FPS_THREADS);
-    else if (ppt <= 2) FPS_LAUNCH(2, true, FPS_THREADS);
-    else if (ppt <= 4) FPS_LAUNCH(4, true, FPS_THREADS);
-    else if (ppt <= 6) FPS_LAUNCH(6, true, FPS_THREADS);
-    else if (ppt <= 8) FPS_LAUNCH(8, true, FPS_THREADS);
+#define FPS_BY_PPT(L, T)                               \
+    do {                                               \
+        if (ppt <= 2) FPS_LAUNCH(2, L, T);             \
+        else if (ppt <= 4) FPS_LAUNCH(4, L, T);        \
+        else if (ppt <= 6) FPS_LAUNCH(6, L, T);        \
+        else if (ppt <= 8) FPS_LAUNCH(8, L, T);        \
+        else if (ppt <= 12) FPS_LAUNCH(12, L, T);      \
+        else if (ppt <= 16) FPS_LAUNCH(16, L, T);      \
+        else FPS_LAUNCH(24, L, T);                     \
+    } while (0)
+    if (threads == 256) FPS_BY_PPT(true, 256);
+    else if (threads == FPS_MID_THREADS && lds_pos) FPS_BY_PPT(true, FPS_MID_THREADS);
+    else if (threads == FPS_MID_THREADS) FPS_BY_PPT(false, FPS_MID_THREADS);
     else FPS_LAUNCH(16, false, FPS_THREADS);
+#undef FPS_BY_PPT
 #undef FPS_LAUNCH
     GN_LAUNCH_CHECK("gn_fps");
     return GN_OK;

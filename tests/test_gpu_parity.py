@@ -48,7 +48,8 @@ def _model(hp, seed):
 
 
 # ------------------------------------------------------------------------------------------------ point ops
-@pytest.mark.parametrize("sizes,ratio", [([6000, 6000], 0.5), ([3000], 0.25), ([700, 1, 333, 64, 65], 0.5), ([9000], 0.25)])
+@pytest.mark.parametrize("sizes,ratio", [([6000, 6000], 0.5), ([3000], 0.25), ([700, 1, 333, 64, 65], 0.5), ([9000], 0.25),
+                                         ([6145, 6144], 0.25), ([8192, 8193], 0.125), ([13000], 0.05)])
 def test_fps_bit_exact(sizes, ratio):
     _, pos, batch = _ragged_cloud(sizes, 3)
     ptr = O.batch_to_ptr(batch.numpy())
@@ -56,6 +57,21 @@ def test_fps_bit_exact(sizes, ratio):
     seg = Segments(sizes, DEV)
     cseg = Segments([ops.fps_count(n, ratio) for n in sizes], DEV)
     assert list(cseg.ptr.cpu().numpy()) == list(optr)
+    idx = ops.fps(pos.to(DEV), seg.ptr, cseg.ptr, max(sizes), cseg.total)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
+
+
+@pytest.mark.parametrize("sizes", [[2000, 700], [6500], [64, 5]])
+def test_fps_ties_keep_the_lowest_index(sizes):
+    """points on a coarse integer lattice, many of them duplicated: most steps see exact ties of the running distance inside a lane, inside a
+    wave and across waves (the ballot short cut's fallback, the DPP min, the cross-wave min) -- the oracle's rule is the lowest index"""
+    g = torch.Generator().manual_seed(7)
+    pos = torch.cat([torch.randint(0, 5, (n, 3), generator=g).float() * 0.25 for n in sizes])
+    batch = torch.cat([torch.full((n,), b, dtype=torch.int64) for b, n in enumerate(sizes)])
+    ptr = O.batch_to_ptr(batch.numpy())
+    ref, optr = O.fps(pos.numpy(), ptr, 0.5)
+    seg = Segments(sizes, DEV)
+    cseg = Segments([ops.fps_count(n, 0.5) for n in sizes], DEV)
     idx = ops.fps(pos.to(DEV), seg.ptr, cseg.ptr, max(sizes), cseg.total)
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
 

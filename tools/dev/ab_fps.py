@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from garmentnets_amd import ops
 dev = 'cuda'
 g = torch.Generator().manual_seed(11)
-for B, n, ratio in ((16, 6000, 0.5), (16, 3000, 0.25), (1, 6000, 0.5), (1, 3000, 0.25), (16, 10000, 0.5), (4, 777, 0.5)):
+for B, n, ratio in ((16, 6000, 0.5), (16, 3000, 0.25), (1, 6000, 0.5), (1, 3000, 0.25), (16, 10000, 0.5), (4, 777, 0.5), (8, 8000, 0.25), (8, 12288, 0.25), (8, 16384, 0.125), (3, 100, 0.5), (2, 6144, 0.5), (2, 6145, 0.5)):
     pos = (torch.rand(B * n, 3, generator=g) - 0.5).to(dev)
     pos[5] = pos[3]                                     # an exact duplicate: ties on the way
     m = ops.fps_count(n, ratio)
