@@ -185,7 +185,31 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
                 }
             GN_WAIT_VM_LGKM0(0);
             __syncthreads();
+            // corners straight from LDS, branch-free: a corner past the volume's upper face reads corner 0 (always inside, always finite when the
+            // query's result is) with weight 0 -- acc + (+-0) == acc exactly and acc is never -0, so the sum is the guarded loop's bit for bit; one
+            // basic block with 16 ds_read_b128 in flight instead of 16 exec-masked blocks around flat loads (the LDS / global pointer select)
+#pragma unroll
+            for (int qn = 0; qn < NQ; ++qn) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int vbase = vidx[qn] * 128 + part * 16;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+                    const bool okc = (okm[qn] >> c) & 1u;
+                    const float w = okc ? wgt[qn][c] : 0.f;
+                    int o = vbase + (((dz * ey + dy) * ex + dx) * 128 & -(int)okc);
+                    asm volatile("" : "+v"(o));           // (opaque: hipcc otherwise turns the select back into 8 exec-masked loads)
+                    const float4 v = *reinterpret_cast<const float4 *>(tb_smem + o);
+                    acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, w));
+                    acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, w));
+                    acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, w));
+                    acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, w));
+                }
+                if (okm[qn] & 256u) *reinterpret_cast<float4 *>(out + mrow[qn] * ldo + cg * 32 + part * 4) = acc;
+            }
+            return;
         }
+        // (a lattice coarser than the volume: the corners come from L2)
 #pragma unroll
         for (int qn = 0; qn < NQ; ++qn) {
             if (!(okm[qn] & 256u)) continue;
@@ -194,9 +218,7 @@ __global__ __launch_bounds__(256) void trilinear_brick_kernel(const float *__res
             for (int c = 0; c < 8; ++c)
                 if (okm[qn] & (1u << c)) {
                     const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-                    float4 v;
-                    if (in_lds) v = *reinterpret_cast<const float4 *>(tb_smem + ((size_t)(vidx[qn] + (dz * ey + dy) * ex + dx) * 32 + part * 4) * 4);
-                    else v = *reinterpret_cast<const float4 *>(vol + (goff[qn] + ((int64_t)dz * H + dy) * W + dx) * C + cg * 32 + part * 4);
+                    const float4 v = *reinterpret_cast<const float4 *>(vol + (goff[qn] + ((int64_t)dz * H + dy) * W + dx) * C + cg * 32 + part * 4);
                     acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, wgt[qn][c]));
                     acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, wgt[qn][c]));
                     acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, wgt[qn][c]));
