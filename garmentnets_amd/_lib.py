@@ -21,6 +21,7 @@ PROTOTYPES = {
     "gn_device_info": [_vp, _vp],
     "gn_segment_ptr": [_vp, _i64, _i32, _vp, _vp],
     "gn_fps": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "gn_fps_nested": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_ball_query": [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp],
     "gn_sa_gather": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp],
     "gn_segment_max": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],

@@ -122,7 +122,15 @@ class SAModule(torch.nn.Module):
         start = None
         if self.random_start:
             start = torch.tensor([int(torch.randint(0, max(n, 1), (1,))) for n in seg.sizes], dtype=torch.int32).to(pos.device)
-        idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total, start)
+        # a cascade's second level samples the points the first one selected, in selection order: farthest-point order is nested, so its sample
+        # is a prefix (include/garmentnets_hip.h gn_fps_nested; decided per example on the device from the first level's smallest running maximum)
+        gap = nested = None
+        if start is None and seg.num > 0:
+            gap = torch.empty(seg.num, dtype=torch.float32, device=pos.device)
+            src = getattr(pos, "_fps_cascade", None)
+            if src is not None and src[1] == seg.sizes and src[2] == pos._version and src[0].device == pos.device:
+                nested = src[0]
+        idx = ops.fps(pos, seg.ptr, cseg.ptr, max(seg.sizes) if seg.sizes else 0, cseg.total, start, gap_out=gap, nested_gap=nested)
         nbr, cnt = ops.ball_query(pos, seg.ptr, idx, cseg.ptr, self.r, 64)
         pack = self._fused_pack() if FUSED_SA else None
         self_src = None
@@ -136,7 +144,10 @@ class SAModule(torch.nn.Module):
             h = self.conv.local_nn(edges)
             out = ops.segment_max(h, slot_src, cseg.total, S)
         _DEBUG.__dict__.setdefault("graphs", weakref.WeakKeyDictionary())[self] = (idx, nbr)
-        return out, pos[idx.long()], cseg
+        pos_out = pos[idx.long()]
+        if gap is not None:
+            pos_out._fps_cascade = (gap, out_sizes, pos_out._version)     # lives on THIS tensor object only: any op on it yields a tensor without it
+        return out, pos_out, cseg
 
     @property
     def last_graph(self):

@@ -135,7 +135,8 @@ __device__ __forceinline__ float fps_min(float a, float b) {
 template <int PPT, bool LDS_POS, int THREADS>
 __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr,
                                                       const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ start_idx,
-                                                      int32_t *__restrict__ out_idx) {
+                                                      int32_t *__restrict__ out_idx, float *__restrict__ gap_out,
+                                                      const float *__restrict__ nested_gap) {
     constexpr int WAVES = THREADS / 64;
     static_assert(PPT == 1 || PPT % 2 == 0, "points are updated in pairs");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -144,6 +145,14 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
     if (n <= 0 || m <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // nested sampling (gn_fps_nested): the example's points ARE an earlier farthest-point sample in selection order, begun at the same point, whose
+    // running maximum stayed positive (nested_gap[b] > 0) -- then this sample is that one's prefix: local indices 0, 1, ..., m-1 (proof at gn_fps_nested)
+    if (nested_gap && nested_gap[b] > 0.f && m <= n) {
+        for (int k = tid; k < m; k += THREADS) out_idx[o0 + k] = s + k;
+        if (gap_out && tid == 0) gap_out[b] = nested_gap[b];      // this sample's running maxima are the first m - 1 of the earlier one's: >= its smallest
+        return;
+    }
+    float gmin = 3.0e38f;                   // smallest running maximum over the steps (gap_out)
     float *pv = smem;                       // [2][WAVES] partial values
     int *pi = (int *)(smem + 2 * WAVES);    // [2][WAVES] partial indices
     float *lx = smem + 4 * WAVES;           // SoA positions (LDS_POS only)
@@ -210,13 +219,16 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
         const float gv = part_max_f<WAVES>(fv);
         fi = part_min_i<WAVES>(fv == gv ? fi : INT_MAX);
         last = __builtin_amdgcn_readfirstlane(fi);
+        gmin = fps_min(gmin, gv);
         if (tid == 0) out_idx[o0 + k] = s + last;
     }
+    if (gap_out && tid == 0) gap_out[b] = gmin;
 }
 
-extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
-                      int max_points_per_example, int32_t *out_idx, void *stream) {
+extern "C" int gn_fps_nested(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
+                             int max_points_per_example, int32_t *out_idx, float *gap_out, const float *nested_gap, void *stream) {
     GN_REQUIRE(B >= 0 && max_points_per_example >= 0, "gn_fps: bad sizes");
+    GN_REQUIRE(nested_gap == nullptr || start_idx == nullptr, "gn_fps_nested: a nested sample starts at the example's first point (start_idx must be NULL)");
     if (B == 0 || max_points_per_example == 0) return GN_OK;
     const int n = max_points_per_example;
     GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
@@ -232,7 +244,7 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
 #define FPS_LAUNCH(P, L, T)                                                                                     \
     do {                                                                                                        \
         GN_HIP(hipFuncSetAttribute((const void *)fps_kernel<P, L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_fps"); \
-        hipLaunchKernelGGL((fps_kernel<P, L, T>), dim3(B), dim3(T), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx); \
+        hipLaunchKernelGGL((fps_kernel<P, L, T>), dim3(B), dim3(T), sh, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx, gap_out, nested_gap); \
     } while (0)
 #define FPS_BY_PPT(L, T)                               \
     do {                                               \
@@ -252,6 +264,11 @@ extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_p
 #undef FPS_LAUNCH
     GN_LAUNCH_CHECK("gn_fps");
     return GN_OK;
+}
+
+extern "C" int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
+                      int max_points_per_example, int32_t *out_idx, void *stream) {
+    return gn_fps_nested(pos, ptr, out_ptr, start_idx, B, max_points_per_example, out_idx, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ ball query

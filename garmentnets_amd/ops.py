@@ -83,11 +83,21 @@ def segment_ptr(batch, B):
     return ptr
 
 
-def fps(pos, ptr, out_ptr, max_points, m_total, start_idx=None):
-    """start_idx: optional int32 [B] local start point per example (None = first point)."""
+def fps(pos, ptr, out_ptr, max_points, m_total, start_idx=None, gap_out=None, nested_gap=None):
+    """start_idx: optional int32 [B] local start point per example (None = first point).
+    gap_out / nested_gap: float32 [B] (include/garmentnets_hip.h gn_fps_nested): a cascade's second level hands in the first level's gap_out and
+    gets the prefix 0..m-1 of every example whose first-level running maximum stayed positive -- the same indices without the serial steps."""
     _chk(pos, torch.float32, "pos")
     idx = torch.empty(m_total, dtype=_i32, device=pos.device)
-    _lib.call("gn_fps", _p(pos), _p(ptr), _p(out_ptr), _p(start_idx), ptr.numel() - 1, int(max_points), _p(idx), _stream())
+    if gap_out is None and nested_gap is None:
+        _lib.call("gn_fps", _p(pos), _p(ptr), _p(out_ptr), _p(start_idx), ptr.numel() - 1, int(max_points), _p(idx), _stream())
+    else:
+        if gap_out is not None:
+            _chk(gap_out, torch.float32, "gap_out")
+        if nested_gap is not None:
+            _chk(nested_gap, torch.float32, "nested_gap")
+        _lib.call("gn_fps_nested", _p(pos), _p(ptr), _p(out_ptr), _p(start_idx), ptr.numel() - 1, int(max_points), _p(idx), _p(gap_out), _p(nested_gap),
+                  _stream())
     return idx
 
 

@@ -52,9 +52,20 @@ int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *ptr, void *s
  * with local point start_idx[b] (start_idx == NULL: the example's first point = torch_cluster random_start=False; the
  * upstream default random_start=True is obtained by passing host-drawn random starts);
  * dist = (dx*dx+dy*dy)+dz*dz in fp32 without FMA; ties -> lowest index.
- * One 1024-thread workgroup per example, positions + running min-distance resident in registers / LDS. */
+ * One workgroup per example (one wave per SIMD up to 24 points per lane), positions + running min-distance resident in registers / LDS. */
 int gn_fps(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
            int max_points_per_example, int32_t *out_idx, void *stream);
+
+/* gn_fps for the CASCADE of components/pointnet2.py:26 (networks/pointnet2_nocs.py:139-141: sa2 samples the points sa1 selected).
+ * gap_out    (NULL or [B] float): the smallest running maximum of the min-distance over this call's steps (3e38 if it took none).
+ * nested_gap (NULL or [B] float): the gap_out of the EARLIER call whose output, in selection order, is this call's `pos` (caller's
+ *            contract; start_idx must be NULL in both).  Farthest-point order is nested: with s_0..s_{m1-1} the earlier selection and
+ *            D_k(i) = min_{j<k} d(i, s_j), position t of the new cloud holds E_k(t) = D_k(s_t) once positions 0..k-1 are chosen -- 0 for
+ *            t < k, at most max_i D_k(i) = D_k(s_k) for t >= k -- so while that maximum is positive position k wins the arg-max and its
+ *            lowest-index tie rule: an example with nested_gap[b] > 0 gets the indices ptr[b] + 0, 1, ..., m-1 without a single step,
+ *            the others (duplicate-ridden clouds) are sampled as gn_fps samples them.  Same output as gn_fps, bit for bit, either way. */
+int gn_fps_nested(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
+                  int max_points_per_example, int32_t *out_idx, float *gap_out, const float *nested_gap, void *stream);
 
 /* Ball query.  replaces torch_cluster.radius(max_num_neighbors=K) -- components/pointnet2.py:28-29.
  * For every centre c (a point index centre_idx[c], example b): the first K points j of example b in ascending

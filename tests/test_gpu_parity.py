@@ -76,6 +76,39 @@ def test_fps_ties_keep_the_lowest_index(sizes):
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
 
 
+def test_fps_nested_sample_is_the_plain_sample():
+    """gn_fps_nested: the second level of the SA cascade (fps over the points the first level selected, in selection order) is a prefix wherever the
+    first level's running maximum stayed positive -- and is sampled step by step where it did not (an example made of duplicated lattice points)"""
+    g = torch.Generator().manual_seed(9)
+    sizes = [6000, 2000, 777, 3000]
+    clouds = [torch.rand(n, 3, generator=g) - 0.5 for n in sizes]
+    clouds[1] = torch.randint(0, 4, (sizes[1], 3), generator=g).float() * 0.25          # 64 distinct points: the running maximum reaches 0
+    pos = torch.cat(clouds).to(DEV)
+    seg = Segments(sizes, DEV)
+    m1 = [ops.fps_count(n, 0.5) for n in sizes]
+    seg1 = Segments(m1, DEV)
+    gap1 = torch.empty(len(sizes), dtype=torch.float32, device=DEV)
+    idx1 = ops.fps(pos, seg.ptr, seg1.ptr, max(sizes), seg1.total, gap_out=gap1)
+    assert torch.equal(idx1, ops.fps(pos, seg.ptr, seg1.ptr, max(sizes), seg1.total))
+    g1 = gap1.cpu().numpy()
+    assert g1[0] > 0 and g1[2] > 0 and g1[3] > 0 and g1[1] == 0
+    pos1 = pos[idx1.long()]
+    m2 = [ops.fps_count(n, 0.25) for n in m1]
+    seg2 = Segments(m2, DEV)
+    gap2 = torch.empty(len(sizes), dtype=torch.float32, device=DEV)
+    plain = ops.fps(pos1, seg1.ptr, seg2.ptr, max(m1), seg2.total)
+    nested = ops.fps(pos1, seg1.ptr, seg2.ptr, max(m1), seg2.total, gap_out=gap2, nested_gap=gap1)
+    assert torch.equal(plain, nested)
+    ref, _ = O.fps(pos1.cpu().numpy(), np.asarray(seg1.ptr.cpu().numpy(), dtype=np.int64), 0.25)
+    assert np.array_equal(nested.cpu().numpy().astype(np.int64), ref)
+    p1, p2 = seg1.ptr.cpu().numpy(), seg2.ptr.cpu().numpy()
+    for b in (0, 2, 3):                                                                  # the prefix, as claimed
+        assert np.array_equal(nested.cpu().numpy()[p2[b]:p2[b + 1]], p1[b] + np.arange(m2[b]))
+    assert np.array_equal(gap2.cpu().numpy()[[0, 2, 3]], g1[[0, 2, 3]]) and gap2.cpu().numpy()[1] == 0
+    # (the module cascade -- SAModule hands the first level's gap to the second through the position tensor it returns -- is held to the oracle's
+    #  indices of BOTH levels by test_sa_module_graph_bit_exact and by every pipeline golden)
+
+
 def test_fps_start_index():
     """random_start plumbing: any start index gives a valid greedy max-min sequence beginning at that point."""
     _, pos, batch = _ragged_cloud([500, 300], 21)
