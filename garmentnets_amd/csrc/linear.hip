@@ -9,16 +9,23 @@
 //
 // Block = 256 threads = 4 waves.  X and W tiles ([rows][16 k], row stride 17 words -> conflict-free
 // ds_read_b32 for 32 consecutive rows) are staged through LDS with a register prefetch of the next k-tile.
+// Round 5 (tools/dev/ab_linear.py): half-height / quarter tiles when the full 128 x 128 tile would leave CUs without a workgroup
+// (12000 x 256: 188 workgroups; 6000 x 128: 47) -- the same k order per output element, bit-identical results; measured and not
+// shipped: 32-deep tiles (LIN_BK 32: no gain, K = 131 pads further) and a double-buffered tile with one barrier (LIN_NBUF 2: costs a
+// workgroup per CU, 20 % slower).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LIN_BK 16
+#ifndef LIN_NBUF
+#define LIN_NBUF 1
+#endif
 #define LIN_LDS_STRIDE (LIN_BK + 1)
 
 template <int ROWS>
 struct TileRegs {
-    static constexpr int NV = (ROWS * 4 + 255) / 256;  // float4 per thread
+    static constexpr int NV = (ROWS * (LIN_BK / 4) + 255) / 256;  // float4 per thread
     float4 v[NV];
 };
 
@@ -30,9 +37,9 @@ __device__ __forceinline__ void tile_load(TileRegs<ROWS> &r, const float *__rest
     for (int i = 0; i < TileRegs<ROWS>::NV; ++i) {
         int idx = threadIdx.x + i * 256;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < ROWS * 4) {
-            int64_t row = row0 + (idx >> 2);
-            int k = k0 + (idx & 3) * 4;
+        if (idx < ROWS * (LIN_BK / 4)) {
+            int64_t row = row0 + idx / (LIN_BK / 4);
+            int k = k0 + (idx % (LIN_BK / 4)) * 4;
             if (row < nrows && k < K) {
                 const float *p = P + row * ld + k;
                 if (ALIGNED) {
@@ -57,8 +64,8 @@ __device__ __forceinline__ void tile_store(const TileRegs<ROWS> &r, float *__res
 #pragma unroll
     for (int i = 0; i < TileRegs<ROWS>::NV; ++i) {
         int idx = threadIdx.x + i * 256;
-        if (idx < ROWS * 4) {
-            float *p = lds + (idx >> 2) * LIN_LDS_STRIDE + (idx & 3) * 4;
+        if (idx < ROWS * (LIN_BK / 4)) {
+            float *p = lds + (idx / (LIN_BK / 4)) * LIN_LDS_STRIDE + (idx % (LIN_BK / 4)) * 4;
             p[0] = r.v[i].x; p[1] = r.v[i].y; p[2] = r.v[i].z; p[3] = r.v[i].w;
         }
     }
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
                                                      float *__restrict__ Y, int ldy) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-    __shared__ float As[BM * LIN_LDS_STRIDE];
-    __shared__ float Bs[BN * LIN_LDS_STRIDE];
+    __shared__ float As[LIN_NBUF][BM * LIN_LDS_STRIDE];
+    __shared__ float Bs[LIN_NBUF][BN * LIN_LDS_STRIDE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -90,13 +97,14 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
     TileRegs<BN> rb;
     tile_load<BM, ALIGNED>(ra, X, ldx, m0, M, 0, K);
     tile_load<BN, ALIGNED>(rb, W, ldw, n0, N, 0, K);
-    tile_store<BM>(ra, As);
-    tile_store<BN>(rb, Bs);
+    tile_store<BM>(ra, As[0]);
+    tile_store<BN>(rb, Bs[0]);
     __syncthreads();
     const int nk = (K + LIN_BK - 1) / LIN_BK;
     const int arow = (wm * TM * 32 + (lane & 31)) * LIN_LDS_STRIDE + (lane >> 5);
     const int brow = (wn * TN * 32 + (lane & 31)) * LIN_LDS_STRIDE + (lane >> 5);
     for (int kt = 0; kt < nk; ++kt) {
+        const float *const Ac = As[kt & (LIN_NBUF - 1)], *const Bc = Bs[kt & (LIN_NBUF - 1)];
         if (kt + 1 < nk) {
             tile_load<BM, ALIGNED>(ra, X, ldx, m0, M, (kt + 1) * LIN_BK, K);
             tile_load<BN, ALIGNED>(rb, W, ldw, n0, N, (kt + 1) * LIN_BK, K);
@@ -105,20 +113,21 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
         for (int kk = 0; kk < LIN_BK / 2; ++kk) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = As[arow + t * 32 * LIN_LDS_STRIDE + kk * 2];
+            for (int t = 0; t < TM; ++t) a[t] = Ac[arow + t * 32 * LIN_LDS_STRIDE + kk * 2];
 #pragma unroll
-            for (int u = 0; u < TN; ++u) b[u] = Bs[brow + u * 32 * LIN_LDS_STRIDE + kk * 2];
+            for (int u = 0; u < TN; ++u) b[u] = Bc[brow + u * 32 * LIN_LDS_STRIDE + kk * 2];
 #pragma unroll
             for (int t = 0; t < TM; ++t)
 #pragma unroll
                 for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
-        __syncthreads();
+        if (LIN_NBUF == 1) __syncthreads();
         if (kt + 1 < nk) {
-            tile_store<BM>(ra, As);
-            tile_store<BN>(rb, Bs);
-            __syncthreads();
+            // the OTHER buffer: everybody left it at the barrier that closed tile kt - 1
+            tile_store<BM>(ra, As[(kt + 1) & (LIN_NBUF - 1)]);
+            tile_store<BN>(rb, Bs[(kt + 1) & (LIN_NBUF - 1)]);
         }
+        __syncthreads();
     }
     // epilogue: bias -> ReLU -> BN affine
 #pragma unroll
@@ -160,9 +169,12 @@ extern "C" int gn_linear(const float *X, int ldx, const float *W, int ldw, const
         else                                                                                                                \
             hipLaunchKernelGGL((linear_kernel<WM, WN, TM, TN, false>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, bn_scale, bn_shift, relu, M, N, K, Y, ldy); \
     } while (0)
+    const int64_t full = gn_cdiv(M, 128) * gn_cdiv(N, 128);   // workgroups of the 128 x 128 tile
     if (N <= 32) LIN_LAUNCH(4, 1, 2, 1);
     else if (N <= 64) LIN_LAUNCH(2, 2, 2, 1);
-    else LIN_LAUNCH(2, 2, 2, 2);
+    else if (full >= 384) LIN_LAUNCH(2, 2, 2, 2);
+    else if (2 * full >= 256) LIN_LAUNCH(2, 2, 1, 2);        // 64 x 128
+    else LIN_LAUNCH(2, 2, 1, 1);                             // 64 x 64
 #undef LIN_LAUNCH
     GN_LAUNCH_CHECK("gn_linear");
     return GN_OK;
