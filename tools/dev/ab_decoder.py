@@ -5,6 +5,7 @@ from garmentnets_amd import ops
 dev = 'cuda'
 g = torch.Generator().manual_seed(5)
 NH = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+REST = len(sys.argv) > 2 and sys.argv[2] == 'rest'     # every row the same (zeros): the same instruction stream on operands that do not toggle
 dims = [32, NH, NH, 1]
 raw = []
 for i in range(3):
@@ -13,6 +14,8 @@ for i in range(3):
 pack = ops.pack_decode_split(raw).to(dev)
 for M in (1000, 2 ** 20, 2 ** 21 + 77, 16 * 2 ** 20):
     x = torch.relu(torch.randn(M, 32, generator=g)) * 2.0
+    if REST:
+        x.zero_()
     xin = ops.new_rows(M, 32, dev); xin.copy_(x.to(dev))
     out = ops.implicit_decode_split(xin, pack); torch.cuda.synchronize()
     reps = 20 if M < 2 ** 22 else 5
