@@ -227,3 +227,20 @@ def test_point_ops_against_plain_torch():
     w = 1.0 / torch.clamp(tv, min=1e-16)
     ref = (feats[ti] * w.unsqueeze(-1)).sum(1) / w.sum(1, keepdim=True)
     np.testing.assert_allclose(y, ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed,n,r1,r2", [(0, 1500, 0.5, 0.25), (1, 999, 0.5, 0.5), (2, 64, 0.75, 0.5)])
+def test_farthest_point_order_is_nested_in_the_oracle(seed, n, r1, r2):
+    """what gn_fps_nested rests on (include/garmentnets_hip.h), shown on the CPU oracle: sampling the points a first farthest-point sample selected, in
+    selection order, from its first point, returns the prefix 0, 1, ..., m2-1 -- as long as no running maximum is zero; a cloud of duplicated lattice
+    points (the guard's other branch) does NOT have the property once its distinct points are used up"""
+    rng = np.random.RandomState(seed)
+    pos = (rng.rand(n, 3) - 0.5).astype(np.float32)
+    ptr = np.array([0, n], dtype=np.int64)
+    idx1, optr1 = O.fps(pos, ptr, r1)
+    second, optr2 = O.fps(pos[idx1], optr1, r2)
+    assert np.array_equal(second, np.arange(optr2[1]))
+    lattice = (rng.randint(0, 3, (200, 3)) * 0.5).astype(np.float32)                     # 27 distinct points
+    l1, lp1 = O.fps(lattice, np.array([0, 200], dtype=np.int64), 0.5)
+    l2, lp2 = O.fps(lattice[l1], lp1, 0.5)
+    assert np.array_equal(l2[:20], np.arange(20)) and not np.array_equal(l2, np.arange(lp2[1]))
