@@ -59,12 +59,12 @@ extern "C" int gn_segment_ptr(const int64_t *batch, int64_t n, int B, int32_t *p
 }
 
 // ------------------------------------------------------------------------------------------------ FPS
-// One 1024-thread workgroup per example.  Thread t owns points t, t+1024, ... (PPT of them) and keeps their
-// coordinates and running min-distance in registers; a SoA copy of the positions lives in LDS so that every
-// thread can fetch the newly selected point by broadcast read.  Per step: fused (min-update, local arg-max),
-// wave arg-max on the DPP crossbar (quad_perm / row_half_mirror / row_mirror + 4 readlanes: max of the distance, then
-// min of the index among the lanes that hold it -> ties go to the lowest index), one LDS exchange of the 16 wave
-// partials (double-buffered by step parity -> a single barrier per step), and a 16-lane DPP reduce of the partials.
+// One workgroup of THREADS (256 / 512 / 1024, see gn_fps_nested) per example.  Thread t owns points t, t+THREADS, ... (PPT of them) and keeps
+// their coordinates and running min-distance in registers; a SoA copy of the positions lives in LDS so that every
+// thread can fetch the newly selected point by broadcast read.  Per step: fused (min-update, local arg-max of the SLOT),
+// wave arg-max on the DPP crossbar (quad_perm / row_half_mirror / row_mirror + 4 readlanes: max of the distance; the index is read
+// from the one lane a ballot names, or -- exact ties -- the DPP min of the indices: ties go to the lowest index), one LDS exchange
+// of the wave partials (double-buffered by step parity -> a single barrier per step), and a log2(waves)-step DPP reduce of the partials.
 #define FPS_THREADS 1024
 #define FPS_WAVES (FPS_THREADS / 64)
 
@@ -119,9 +119,8 @@ __device__ __forceinline__ int wave_min_i(int v) {
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// THREADS = 256 (one wave per SIMD, up to 24 points per thread) for clouds of up to 6144 points: a step costs what its instructions
-// cost in issue slots -- the min-update is the same work however it is spread, but the arg-max reduction (2 x 6 DPP steps + the
-// cross-wave exchange, ~60 instructions per wave) is paid once per wave: 4 waves per SIMD spent as long in it as in the update.
+// One wave per SIMD for as long as the points fit the registers (24 per lane): a step costs what its instructions cost in issue slots -- the
+// min-update is the same work however it is spread, but the arg-max reduction and the cross-wave exchange are paid once per wave.
 // The update itself runs on point PAIRS in packed fp32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, half the issue slots).
 typedef float fps_f2 __attribute__((ext_vector_type(2)));
 // running minimum in ONE instruction: fminf() compiles to two canonicalising v_max_f32 + v_min_f32 under the IEEE mode bit (3 instructions per point in a
