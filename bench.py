@@ -144,8 +144,9 @@ class KernelTimer:
             e0.record()
             out = orig(*a, **kw)
             e1.record()
-            name, work, byts = describe(out, *a, **kw)
-            timer.records.append((name, work, byts, e0, e1))
+            d = describe(out, *a, **kw)
+            if d is not None:                       # (None: a launch the roofline does not count, e.g. the gated no-op fp32 twin)
+                timer.records.append(d + (e0, e1))
             return out
         return timed
 
@@ -179,6 +180,45 @@ class KernelTimer:
         ops.conv3d_gcr_split_persample = self._wrap(ops.conv3d_gcr_split_persample, describe_ps)
         ops.conv3d_gcr_split = self._wrap(ops.conv3d_gcr_split, describe)
         ops.upconv_partial = self._wrap(ops.upconv_partial, describe_up)
+
+    def install_decoder(self):
+        """the implicit-decoder launches (networks/conv_implicit_wnf.py:128-149 of the reference): sampler = HBM-bound, MLP = matrix cores.  FLOPs are the
+        EXECUTED network's (the folded first layer where the pack is folded), names are what rocprofv3 prints for the same launches"""
+        from garmentnets_amd import ops
+
+        def mlp_flops(c0, n, outc, rows):
+            return 2.0 * (c0 * n + n * n + n * outc) * rows
+
+        def d_split(res_, xin, pack, out=None, xscale=None):
+            M, c0 = xin.shape
+            n, oc = pack.hidden, pack.out_channels
+            name = f"implicit_decode_split512_kernel<{oc}>" if n == 512 else f"implicit_decode_split_kernel<{oc}, {c0 // 16}, false>"
+            return name, mlp_flops(c0, n, oc, M), (c0 + oc) * 4.0 * M + pack.wpack.numel() * 2.0
+
+        def d_lattice(res_, vol_b, Q, pack, out, xscale=None, m0=0, M=None):
+            M = Q * Q * Q - m0 if M is None else M
+            c0 = vol_b.shape[-1]
+            return ("implicit_decode_split_kernel<1, 2, true>", mlp_flops(c0, pack.hidden, pack.out_channels, M),
+                    vol_b.numel() * 4.0 * M / float(Q) ** 3 + 4.0 * M + pack.wpack.numel() * 2.0)
+
+        def d_fp32(res_, vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=None, run_if=None):
+            if run_if is not None:
+                return None                          # gated twin behind a split launch: a no-op unless the device flagged the garment (fp32_twin in the detail file)
+            (w1p, _, _, _, n1), (_, _, _, _, n2), (_, _, _, _, oc) = layers
+            c0 = xin.shape[1] if xin is not None else vol_b.shape[-1]
+            rows = xin.shape[0] if xin is not None else (query.shape[0] if query is not None else M)
+            return f"implicit_decode_kernel<{oc}>", 2.0 * (c0 * n1 + n1 * n2 + n2 * oc) * rows, (c0 + oc) * 4.0 * rows + (c0 * n1 + n1 * n2) * 4.0
+
+        def d_samp(res_, vol_b, query=None, Q=0, m0=0, M=None, **k):
+            rows = query.shape[0] if query is not None else M
+            frac = 1.0 if query is not None or not Q else rows / float(Q) ** 3
+            c = vol_b.shape[-1]
+            return ("trilinear_kernel" if query is not None else "trilinear_brick_kernel"), 0.0, rows * c * 4.0 + frac * vol_b.numel() * 4.0
+
+        ops.implicit_decode_split = self._wrap(ops.implicit_decode_split, d_split)
+        ops.implicit_decode_lattice_split = self._wrap(ops.implicit_decode_lattice_split, d_lattice)
+        ops.implicit_decode = self._wrap(ops.implicit_decode, d_fp32)
+        ops.trilinear_sample = self._wrap(ops.trilinear_sample, d_samp)
 
     def install_points(self):
         """PointNet++ operators (config[1]): work = squared-distance evaluations for fps / ball query / kNN, FLOPs for the GEMMs"""
@@ -501,8 +541,60 @@ def measure_traffic(args):
                              f"({time.time() - t0:.0f} s); FETCH_SIZE x per-kernel gfx950 factor (tools/pmc_summary.py), WRITE_SIZE as reported")
 
 
+def is_conv_group(name):
+    return name.startswith("conv3d") or name.startswith("upconv")
+
+
+def is_decoder_group(name):
+    return name.startswith("implicit_decode")
+
+
+def pick_roofline(args, groups, conv_mode, decode_mode, hw=None, traffic=None):
+    """the roofline of the kernel with the MOST TIME in it during the timed steps, over every bracketed group (convolutions, decoder MLPs, sampler,
+    PointNet++ operators) -- at Q = 256 or G = 32 that is the decoder MLP, not a convolution.  `by_group_ms` lists the contenders."""
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    if is_conv_group(key):
+        rl = conv_roofline(args, {k: v for k, v in groups.items() if is_conv_group(k)}, conv_mode, hw, traffic)
+    elif is_decoder_group(key):
+        rl = decoder_roofline(groups, key, decode_mode, hw, traffic)
+    else:
+        rl = points_roofline({k: v for k, v in groups.items() if not (is_conv_group(k) or is_decoder_group(k))})
+    total = sum(v["ms"] for v in groups.values())
+    rl["share_of_bracketed_ms"] = groups[rl["kernel"]]["ms"] / total if total > 0 else None
+    rl["by_group_ms"] = {k: round(v["ms"], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
+    return rl
+
+
+def decoder_roofline(groups, key, decode_mode, hw=None, traffic=None):
+    """the implicit decoder's MLP kernel (csrc/decode_split.hip, csrc/decode.hip): algorithmic FLOPs of the executed network / HIP-event time"""
+    g = groups[key]
+    sec = g["ms"] * 1e-3
+    achieved = g["work"] / sec / 1e12
+    split = "split" in key
+    n = SPLIT_PRODUCTS["f16x2"] if split else 1
+    peak = PEAK_16BIT_MFMA_TFLOPS / n if split else PEAK_FP32_MFMA_TFLOPS
+    tr, src, tr_detail = None, None, None
+    if traffic is not None:
+        table, src = traffic
+        if table is not None and key in table:
+            tr, tr_detail = table[key]["hbm_bytes"], table[key]
+    out = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+           "peak_note": (f"16-bit MFMA dense peak {PEAK_16BIT_MFMA_TFLOPS:.0f} / {n} executed f16 products per fp32 product (hi*hi + hi*lo + lo*hi); "
+                         f"executed {achieved * n:.0f} TFLOP/s" if split else "fp32 MFMA dense peak"),
+           "traffic": tr, "traffic_source": src, "traffic_detail": tr_detail, "launches": g["n"], "avg_launch_ms": g["ms"] / g["n"],
+           "flops_per_launch": g["work"] / g["n"], "algorithmic_bytes_per_launch": g["bytes"] / g["n"],
+           "hbm_frac_of_8TBs": g["bytes"] / sec / 1e9 / PEAK_HBM_GBS,
+           "all_decoder_instances": {k: {"launches": v["n"], "ms": v["ms"], "tflops": v["work"] / (v["ms"] * 1e-3) / 1e12}
+                                     for k, v in groups.items() if is_decoder_group(k)}}
+    if hw is not None:
+        sclk = hw.get("sclk_mhz")
+        out.update(sclk_mhz=sclk, socket_power_w=hw.get("socket_power_w"), power_cap_w=hw.get("power_cap_w"),
+                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None, hwmon=hw)
+    return out
+
+
 def conv_roofline(args, groups, conv_mode, hw=None, traffic=None):
-    """hw: HwmonSampler.summary() of the pass; traffic: (measure_traffic's kernel table, note) of this run"""
+    """groups: the convolution groups only; hw: HwmonSampler.summary() of the pass; traffic: (measure_traffic's kernel table, note) of this run"""
     key = max(groups, key=lambda k: groups[k]["ms"])
     g = groups[key]
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12          # algorithmic (fp32) FLOPs: 54*Cin*Cout per voxel
@@ -537,7 +629,7 @@ def conv_roofline(args, groups, conv_mode, hw=None, traffic=None):
     if hw is not None:
         sclk = hw.get("sclk_mhz")
         out.update(sclk_mhz=sclk, socket_power_w=hw.get("socket_power_w"), power_cap_w=hw.get("power_cap_w"),
-                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None, throttle=hw.get("throttle"),
+                   frac_at_2400mhz=(out["frac"] * 2400.0 / sclk) if sclk else None,
                    clock_note="sclk / socket power: mean of the GPU's hwmon nodes sampled every 50 ms during this pass (all kernels of the step, "
                               "not the dominant one alone); the peak assumes 2400 MHz, frac_at_2400mhz = frac x 2400 / sclk is the matrix-core "
                               "issue rate the kernel sustains per clock; busy counters: profiles/", hwmon=hw)
@@ -564,6 +656,97 @@ def points_roofline(groups):
     rl["frac"] = rl["achieved"] / rl["peak"]
     rl.update(traffic=None, launches=g["n"], avg_launch_ms=g["ms"] / g["n"], per_operator=per)
     return rl
+
+
+COMPACT_LIMIT = 6144            # bytes: the driver recovers the line from the tail of stdout (round 5's 21.6 KB line did not survive it)
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "value_is", "with_host_io", "two_in_flight_with_host_io", "literal_affine", "strict_fp32",
+                "occupancy_aware", "latency_b1_ms", "stages_ms", "oracle_check", "validation_ok", "rccl_ranks_seen", "dist_backend", "per_rank",
+                "scaling_vs_n1", "detail")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches",
+                 "share_of_bracketed_ms", "sclk_mhz", "socket_power_w", "ppt_residency")
+
+
+def _sig(x, n=5):
+    """numbers to n significant digits (the line is read by a parser and by people; the detail file keeps every digit)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    return float(f"{float(x):.{n}g}")
+
+
+def _short_roofline(rl):
+    if rl is None:
+        return None
+    hw = rl.get("hwmon") or {}
+    thr = hw.get("throttle") or rl.get("throttle") or {}
+    d = {k: _sig(rl.get(k)) for k in ROOFLINE_KEYS if k != "ppt_residency"}
+    d["ppt_residency"] = _sig(thr.get("ppt_power_limit_residency"))
+    return d
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line rank 0 prints on stdout: the contract's keys first and only scalars / short strings, <= COMPACT_LIMIT bytes (tests/test_bench_line.py);
+    everything else of `full` (hwmon traces, throttle residencies, hbm_members, per-kernel tables, the prose) goes to the detail file and to stderr."""
+    cfg = full.get("config") or {}
+    wl = cfg.get("workload") or ""
+    short_cfg = {"workload": wl.split("; input:")[0], "input": cfg.get("input"), "batch_per_gpu": cfg.get("batch_per_gpu"), "global_batch": cfg.get("global_batch"),
+                 "points": cfg.get("points"), "grid": cfg.get("grid"), "reduce": cfg.get("reduce"), "volume_size": cfg.get("volume_size"),
+                 "mesh_verts_per_garment": _sig(cfg.get("mesh_verts_per_garment")), "parallelism": (cfg.get("parallelism") or "").split(" (")[0]}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    out["value"], out["ms_per_step"] = _sig(out["value"], 6), _sig(out["ms_per_step"], 6)
+    out["dtype"] = full.get("dtype_short") or ((full.get("dtype") or "").split(" on the 16-bit")[0] + (", fp32 accumulation)" if " on the 16-bit" in (full.get("dtype") or "") else ""))
+    out["data"] = full.get("data")
+    out["config"] = short_cfg
+    out["roofline"] = _short_roofline(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = None if cb is None else {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                                   "sample": cb["sample"].split(", oracle/")[0][:160]}
+    out["value_is"] = "inputs resident in HBM, results left on the device (bench contract); with_host_io = SURVEY 8d: H2D clouds + D2H meshes inside the timed region"
+    sub = lambda name: full.get(name) or {}
+    pair = lambda name: ({"value": _sig(sub(name).get("value")), "ms_per_step": _sig(sub(name).get("ms_per_step"))} if full.get(name) else None)
+    out["with_host_io"] = pair("with_host_io")
+    out["two_in_flight_with_host_io"] = pair("two_in_flight_with_host_io")
+    for name in ("literal_affine", "strict_fp32"):
+        if full.get(name):
+            rl = sub(name).get("roofline") or {}
+            out[name] = {"value": _sig(sub(name).get("value")), "kernel": rl.get("kernel"), "frac": _sig(rl.get("frac")), "achieved": _sig(rl.get("achieved")),
+                         "peak": _sig(rl.get("peak")), "sclk_mhz": _sig(rl.get("sclk_mhz"))}
+        else:
+            out[name] = None
+    out["occupancy_aware"] = pair("occupancy_aware")
+    out["latency_b1_ms"] = _sig(sub("latency_b1").get("ms_median")) if full.get("latency_b1") else None
+    st = full.get("stages_ms")
+    out["stages_ms"] = None if st is None else {k.split(" (")[0]: _sig(v, 4) for k, v in st.items()}
+    oc = full.get("oracle_check")
+    out["oracle_check"] = None if oc is None else {k: _sig(oc.get(k)) for k in ("ok", "wnf_max_abs_err", "nocs_bins_equal", "occupied_cells_equal", "features_max_abs_err")
+                                                   if k in oc}
+    out["validation_ok"] = (full.get("validation") or {}).get("ok")
+    out["rccl_ranks_seen"] = full.get("rccl_ranks_seen")
+    out["dist_backend"] = full.get("dist_backend")
+    pr = full.get("per_rank") or {}
+    out["per_rank"] = {"slowest_over_fastest": _sig(pr.get("slowest_over_fastest")),
+                       "garments_per_s": [_sig(v, 4) for v in (pr.get("garments_per_s") or [])][:16]}
+    out["scaling_vs_n1"] = _sig(full.get("scaling_vs_n1"))
+    out["detail"] = detail_path
+    assert tuple(out) == COMPACT_KEYS, tuple(out)
+    return out
+
+
+def emit(full):
+    """detail -> gpurun_out/bench_detail.json (+ stderr), the compact line -> stdout, LAST"""
+    detail_path = None
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        detail_path = os.path.join("gpurun_out", "bench_detail.json")
+        with open(os.path.join(REPO, detail_path), "w") as f:
+            json.dump(full, f)
+    except OSError:
+        detail_path = None
+    print("[bench detail] " + json.dumps(full), file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(full, detail_path))
+    assert len(text) <= COMPACT_LIMIT, len(text)
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def bench_inputs(batch, points, grid, reduce, input_kind, rank=0, world=1):
@@ -715,8 +898,10 @@ def main():
     timer = KernelTimer()
     if args.workload == "pointnet2":
         timer.install_points()
-    else:
+    else:                       # every matrix-core / scan operator of the step is bracketed: the roofline names the one with the most time in it
         timer.install_conv()
+        timer.install_decoder()
+        timer.install_points()
 
     # the model's arithmetic is a per-model immutable value (garmentnets_amd/arith.py): each pass installs its own
     headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False, winograd=args.winograd == "on")    # dense, occupancy-independent
@@ -978,12 +1163,13 @@ def main():
                 traffic = (None, "--no-pmc" if args.no_pmc else "not collected at N > 1 (single-GPU measurement: run bench.py --gpus 1)")
             else:
                 traffic = measure_traffic(args)
-            roofline = conv_roofline(args, groups, args.conv_mode, hw_passes.get("headline"), traffic)
+            roofline = pick_roofline(args, groups, args.conv_mode, args.decode_mode, hw_passes.get("headline"), traffic)
         line = {
             "metric": metric, "value": garments / tmax, "unit": "garments/s", "input": args.input,
             "mesh_verts_per_garment": (verts_total / (hi - lo)) if verts_total is not None else None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
+            "dtype": dtype, "dtype_short": "f32" if dtype == "f32" else f"f32 ({args.conv_mode if split else 'fp32'} convs, {args.decode_mode} decoder MLPs, fp32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": workload, "input": args.input, "batch_per_gpu": args.batch, "global_batch": global_batch,
                        "sharding": f"garments [r*{args.batch}, (r+1)*{args.batch}) of one seeded global batch per rank (parallel.shard_range)",
                        "points": args.points, "grid": args.grid, "reduce": args.reduce,
@@ -1038,7 +1224,7 @@ def main():
             ts = max(r[2] for r in per_rank)
             line["strict_fp32"] = {"value": garments / ts, "unit": "garments/s", "ms_per_step": 1e3 * ts / args.steps, "steps": args.steps,
                                    "dtype": "f32 (v_mfma_f32_32x32x2_f32 convs + fp32 decoder MLPs: --conv-mode fp32 --decode-mode fp32)",
-                                   "roofline": conv_roofline(args, strict[1], "fp32", hw_passes.get("strict_fp32"))}
+                                   "roofline": pick_roofline(args, strict[1], "fp32", "fp32", hw_passes.get("strict_fp32"))}
         if hostio:
             th = max(r[3] for r in per_rank)
             line["with_host_io"] = {"value": garments / th, "unit": "garments/s", "ms_per_step": 1e3 * th / args.steps, "steps": args.steps,
@@ -1060,7 +1246,7 @@ def main():
                         "(every voxel of the >= 99.7 % empty volume non-zero) instead of in per-sample weights + a bias table -- the same MACs through the same "
                         "kernels; the difference is clock under the socket's power cap (DESIGN.md 4.3).  This is the occupancy-INDEPENDENT "
                         "figure: quote it next to the headline",
-                "roofline": conv_roofline(args, groups_l, args.conv_mode, hw_passes.get("literal_affine"))}
+                "roofline": pick_roofline(args, groups_l, args.conv_mode, args.decode_mode, hw_passes.get("literal_affine"))}
         if validation is not None:
             line["validation"] = validation
         if world == 1 and not args.no_cpu_baseline:
@@ -1069,7 +1255,7 @@ def main():
             line["cpu_baseline"], check = cpu_baseline(args, hp, sd, shard, probe)
             if check is not None:
                 line["oracle_check"] = check
-        print(json.dumps(line))
+        emit(line)
         if validation is not None and not validation["ok"]:
             raise SystemExit("bench.py: validation failed (identical garments gave different results in slot 0 and the last slot)")
         if line.get("oracle_check") is not None and not line["oracle_check"]["ok"]:
