@@ -47,6 +47,7 @@ PROTOTYPES = {
     "gn_conv_affine_pack_wino_bytes": [_i32, _i32, _i32],
     "gn_conv_affine_pack_wino": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "gn_conv3d_gcr_split_wino": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp],
+    "gn_conv3d_gcr_split_wino_partial": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "gn_affine_act": [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "gn_upconv_partial": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "gn_grid_tile_flags": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -1021,10 +1021,14 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     // the full-resolution source with 32-bit byte offsets)
     const bool wide128 = !wino && mode != GN_SPLIT_BF16X3 && Cout % 128 == 0 && Cin_total <= 384 && fits32 && (int64_t)tiles * (Cout / 128) * B >= 512;
     // Winograd F(2,3)-along-x form of the 128-wide kernel (unet_wino.hip): its own pack order (36 steps per slice), whole tiles only
-    GN_REQUIRE(!wino || (mode == GN_SPLIT_F16X2 && C1 == 0 && !partial && Cout % 128 == 0 && C0 <= 256 && fits32 && D % SP_TZ == 0 && H % SP_TY == 0 &&
-                         W % SP_TX == 0 && (int64_t)D * H * W <= ((int64_t)1 << 27)),
+    // ... and of the 32-wide column-block kernel (unet_wino32.hip: Cout % 128 != 0): 8 x 8 x 8 tiles, Cin <= 128, a polyphase partial allowed
+    const bool wino32 = wino && Cout % 128 != 0;
+    GN_REQUIRE(!wino || wino32 || (mode == GN_SPLIT_F16X2 && C1 == 0 && !partial && Cout % 128 == 0 && C0 <= 256 && fits32 && D % SP_TZ == 0 && H % SP_TY == 0 &&
+                                   W % SP_TX == 0 && (int64_t)D * H * W <= ((int64_t)1 << 27)),
                "gn_conv3d_gcr_split_wino: needs one source, Cin <= 256, Cout %% 128 == 0, D %% 4 == H %% 8 == W %% 8 == 0, D*H*W <= 2^27 and "
                "D*H*W*Cin*4 < 2^32");
+    GN_REQUIRE(!wino32 || (mode == GN_SPLIT_F16X2 && C1 == 0 && C0 <= 128 && fits32 && D % 8 == 0 && H % 8 == 0 && W % 8 == 0 && (int64_t)D * H * W <= ((int64_t)1 << 27)),
+               "gn_conv3d_gcr_split_wino (Cout %% 128 != 0): needs one source, Cin <= 128, D %% 8 == H %% 8 == W %% 8 == 0, D*H*W <= 2^27 and D*H*W*Cin*4 < 2^32");
     // x-strip variant (below) also for the 64-wide layers with one full-resolution source: two 32-wide column blocks through the strip kernel
     // (18 fragment reads per 36 MFMAs) beat the 64-wide form of conv3d_split_kernel (8 per 12) by 4-7 % on every such shape of the UNet, the
     // halo staged twice notwithstanding (profiles/r04_ab_experiments.txt); bit-identical outputs
@@ -1053,14 +1057,17 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
         GN_REQUIRE(occ_ws && occ_ws_bytes >= gn_conv3d_occupancy_workspace_bytes(B, D, H, W) && ((uintptr_t)occ_ws & 3) == 0,
                    "gn_conv3d_gcr_split: the occupancy-aware launch needs gn_conv3d_occupancy_workspace_bytes(B, D, H, W) bytes of workspace");
         GN_REQUIRE(Cout % 4 == 0 && Cout <= 1024, "gn_conv3d_gcr_split: the occupancy-aware launch needs Cout <= 1024");
-        const int pair = strip ? 2 : 1;
+        const int pair = (strip || wino32) ? 2 : 1;
         int *count = (int *)occ_ws, *list = count + 16;
         hipLaunchKernelGGL(occ_compact_kernel, dim3(1), dim3(1024), 0, st, tile_active, B, tz, p.tiles_y * p.tiles_x, pair, list, count);
         hipLaunchKernelGGL(conv_fill_inactive_kernel, dim3(p.tiles_y * p.tiles_x, B), dim3(256), 0, st, p, tile_active, pair);
         p.active_list = list;
         p.active_count = count;
     }
-    if (wino) {
+    if (wino32) {
+        gn_launch_conv3d_wino32(p, tiles8, st);
+        gn_note_kernel("conv3d_split_wino32_kernel<true>");
+    } else if (wino) {
         gn_launch_conv3d_wino(p, tiles, st);
         gn_note_kernel("conv3d_split_wino_kernel<true>");
     } else if (strip) {
@@ -1106,13 +1113,32 @@ extern "C" int gn_conv3d_gcr_split_persample(const float *src, int Cin, const fl
 // operand forms: kbias == NULL -> the literal form (a, d = the GroupNorm affine incl. the sample's activation scale, act_inv_scale its
 // inverse or NULL, pack = ops.pack_conv_weight_split_wino, out_scale [Cout]); kbias != NULL -> the affine-in-weights form (everything from
 // gn_conv_affine_pack_wino: a, d = the staging affine, per-sample packs, out_scale [B][Cout], act_inv_scale NULL).
+static int conv3d_wino_entry(const float *src, int Cin, const float *a, const float *d, const void *pack, const float *out_scale,
+                             const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                             double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
+                             const float *partial, void *occ_ws, size_t occ_ws_bytes, void *stream) {
+    GN_REQUIRE(pack != nullptr && Cin > 0 && Cin % SP_KS == 0 && Cout > 0 && Cout % 32 == 0, "gn_conv3d_gcr_split_wino: pack, Cin %% 16 == 0 and Cout %% 32 == 0 are required");
+    GN_REQUIRE(!(kbias && act_inv_scale), "gn_conv3d_gcr_split_wino: the affine-in-weights form carries its scales in out_scale [B][Cout]");
+    GN_REQUIRE(!partial || Cout % 128 != 0, "gn_conv3d_gcr_split_wino32: a polyphase partial goes with the 32-wide column-block kernel (Cout %% 128 != 0)");
+    const int64_t per_sample = kbias ? (int64_t)(Cin / SP_KS) * 36 * (Cout / 32) * 2 * 1024 : 0;
+    return conv3d_gcr_split_impl(src, Cin, nullptr, 0, a, d, pack, GN_SPLIT_F16X2, out_scale, act_inv_scale, B, D, H, W, Cout, relu, out, out_sum,
+                                 out_sumsq, tile_active, kconst, kreach, partial, kbias, per_sample, kbias ? Cout : 0, occ_ws, occ_ws_bytes, stream, 1);
+}
+
 extern "C" int gn_conv3d_gcr_split_wino(const float *src, int Cin, const float *a, const float *d, const void *pack, const float *out_scale,
                                         const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                                         double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
                                         void *occ_ws, size_t occ_ws_bytes, void *stream) {
-    GN_REQUIRE(pack != nullptr && Cin > 0 && Cin % SP_KS == 0 && Cout > 0 && Cout % 128 == 0, "gn_conv3d_gcr_split_wino: pack, Cin %% 16 == 0 and Cout %% 128 == 0 are required");
-    GN_REQUIRE(!(kbias && act_inv_scale), "gn_conv3d_gcr_split_wino: the affine-in-weights form carries its scales in out_scale [B][Cout]");
-    const int64_t per_sample = kbias ? (int64_t)(Cin / SP_KS) * 36 * (Cout / 32) * 2 * 1024 : 0;
-    return conv3d_gcr_split_impl(src, Cin, nullptr, 0, a, d, pack, GN_SPLIT_F16X2, out_scale, act_inv_scale, B, D, H, W, Cout, relu, out, out_sum,
-                                 out_sumsq, tile_active, kconst, kreach, nullptr, kbias, per_sample, kbias ? Cout : 0, occ_ws, occ_ws_bytes, stream, 1);
+    return conv3d_wino_entry(src, Cin, a, d, pack, out_scale, act_inv_scale, kbias, B, D, H, W, Cout, relu, out, out_sum, out_sumsq, tile_active, kconst,
+                             kreach, nullptr, occ_ws, occ_ws_bytes, stream);
+}
+
+// The same entry with the polyphase partial of a decoder's first convolution (gn_upconv_partial, upconv.hip) added before the ReLU -- the 32- / 64-wide
+// layers only (unet_wino32.hip; the 128-wide Winograd kernel has no layer that needs it)
+extern "C" int gn_conv3d_gcr_split_wino_partial(const float *src, int Cin, const float *a, const float *d, const void *pack, const float *out_scale,
+                                                const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                                                double *out_sum, double *out_sumsq, const float *partial, void *stream) {
+    GN_REQUIRE(partial != nullptr, "gn_conv3d_gcr_split_wino_partial: partial is required (gn_conv3d_gcr_split_wino is the entry without one)");
+    return conv3d_wino_entry(src, Cin, a, d, pack, out_scale, act_inv_scale, kbias, B, D, H, W, Cout, relu, out, out_sum, out_sumsq, nullptr, nullptr,
+                             1, partial, nullptr, 0, stream);
 }

@@ -355,10 +355,12 @@ def pack_conv_weight_split(w, mode):
 
 
 def wino_supported(cin, cout, dims):
-    """shapes gn_conv3d_gcr_split_wino takes (csrc/unet_wino.hip): one source, whole 4 x 8 x 8 tiles, 32-bit byte offsets inside a sample"""
+    """shapes gn_conv3d_gcr_split_wino takes: one source, 32-bit byte offsets inside a sample, and whole 4 x 8 x 8 tiles with Cin <= 256 for the 128-wide
+    kernel (Cout % 128 == 0, csrc/unet_wino.hip) / whole 8 x 8 x 8 tiles with Cin <= 128 for the 32-wide column-block kernel (csrc/unet_wino32.hip)"""
     D, H, W = [int(v) for v in dims]
-    return (cin % 16 == 0 and cin <= 256 and cout % 128 == 0 and D % 4 == 0 and H % 8 == 0 and W % 8 == 0 and D * H * W <= (1 << 27)
-            and D * H * W * cin * 4 < (1 << 32))
+    if not (cin % 16 == 0 and cout % 32 == 0 and H % 8 == 0 and W % 8 == 0 and D * H * W <= (1 << 27) and D * H * W * cin * 4 < (1 << 32)):
+        return False
+    return (cin <= 256 and D % 4 == 0) if cout % 128 == 0 else (cin <= 128 and D % 8 == 0)
 
 
 def pack_conv_weight_split_wino(w):
@@ -381,11 +383,18 @@ def pack_conv_weight_split_wino(w):
     return SplitPack(pk.contiguous().view(torch.int16), SPLIT_F16X2, (1.0 / scale).float().contiguous())
 
 
-def conv3d_gcr_split_wino(src, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1):
-    """the literal form through the Winograd kernel (pack = pack_conv_weight_split_wino)"""
+def conv3d_gcr_split_wino(src, a, d, pack, cout, relu=True, with_stats=False, act_inv=None, tile_active=None, kconst=None, kreach=1, partial=None):
+    """the literal form through the Winograd kernels (pack = pack_conv_weight_split_wino); partial: the polyphase partial of a decoder's first
+    convolution (upconv_partial), 32- / 64-wide layers only"""
     B, D, H, W, C0 = src.shape
     out = torch.empty((B, D, H, W, cout), dtype=torch.float32, device=src.device)
     s, q = _stats_buffers(B, cout, src.device, with_stats)
+    if partial is not None:
+        if tile_active is not None:
+            raise ValueError("conv3d_gcr_split_wino: the occupancy-aware launch cannot take a polyphase partial")
+        _lib.call("gn_conv3d_gcr_split_wino_partial", _p(src), C0, _p(a), _p(d), _p(pack.tensor), _p(pack.out_scale), _p(act_inv), None, B, D, H, W, cout,
+                  1 if relu else 0, _p(out), _p(s), _p(q), _p(_chk(partial, torch.float32, "partial")), _stream())
+        return (out, (s, q, D * H * W)) if with_stats else out
     ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src.device)
     _lib.call("gn_conv3d_gcr_split_wino", _p(src), C0, _p(a), _p(d), _p(pack.tensor), _p(pack.out_scale), _p(act_inv), None, B, D, H, W, cout,
               1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(ows), ows_bytes, _stream())
@@ -519,7 +528,11 @@ def conv3d_gcr_split_persample(src, prep, relu=True, with_stats=False, tile_acti
     ows, ows_bytes = _occupancy_ws(tile_active, B, D, H, W, src.device)
     if prep.wino:
         if partial is not None:
-            raise ValueError("conv3d_gcr_split_persample: the Winograd pack cannot take a polyphase partial")
+            if tile_active is not None:
+                raise ValueError("conv3d_gcr_split_persample: the occupancy-aware launch cannot take a polyphase partial")
+            _lib.call("gn_conv3d_gcr_split_wino_partial", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), None, _p(prep.kbias),
+                      B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(_chk(partial, torch.float32, "partial")), _stream())
+            return (out, (s, q, D * H * W)) if with_stats else out
         _lib.call("gn_conv3d_gcr_split_wino", _p(src), C, _p(prep.stage_a), _p(prep.stage_d), _p(prep.pack), _p(prep.out_scale), None, _p(prep.kbias),
                   B, D, H, W, prep.cout, 1 if relu else 0, _p(out), _p(s), _p(q), _p(tile_active), _p(kconst), int(kreach), _p(ows), ows_bytes, _stream())
         return (out, (s, q, D * H * W)) if with_stats else out

@@ -262,8 +262,12 @@ int gn_conv3d_gcr_split_persample(const float *src, int Cin, const float *stage_
  *                  (garmentnets_amd.ops.pack_conv_weight_split_wino); out_scale [Cout].
  *   kbias != NULL: the affine-in-weights form -- a, d, pack, out_scale [B][Cout], kbias [B][64][Cout] from gn_conv_affine_pack_wino
  *                  (same contract as gn_conv_affine_pack, 36 steps per slice: gn_conv_affine_pack_wino_bytes); act_inv_scale NULL.
- * Requirements (GN_EINVAL otherwise): one source, Cin % 16 == 0, Cin <= 256, Cout % 128 == 0, D % 4 == H % 8 == W % 8 == 0,
- * D*H*W <= 2^27, D*H*W*Cin*4 < 2^32.  tile_active / kconst / kreach / occ_ws as gn_conv3d_gcr_split. */
+ * Requirements (GN_EINVAL otherwise): one source, Cin % 16 == 0, D*H*W <= 2^27, D*H*W*Cin*4 < 2^32 and
+ *   Cout % 128 == 0 (csrc/unet_wino.hip: 4 x 8 x 8 tiles x 128 channels): Cin <= 256, D % 4 == H % 8 == W % 8 == 0;
+ *   any other Cout % 32 == 0 (csrc/unet_wino32.hip, round 6: 8 x 8 x 8 tiles x one 32-wide column block -- the encoder's second convolution 128 -> 32 at
+ *   full resolution, components/unet3d.py:127-144, and the last decoder's convolutions, :291,330): Cin <= 128, D % 8 == H % 8 == W % 8 == 0.
+ * tile_active / kconst / kreach / occ_ws as gn_conv3d_gcr_split (tile granularity of the occupancy-aware list: the kernel's own).
+ * gn_conv3d_gcr_split_wino_partial: the same layer with the polyphase partial of gn_upconv_partial added before the ReLU (Cout % 128 != 0 only; dense). */
 size_t gn_conv_affine_pack_wino_bytes(int B, int Cin, int Cout);
 int gn_conv_affine_pack_wino(const float *w, int Cin, int Cout, const float *a, const float *d, const double *sum, const double *sumsq, int64_t V,
                              const float *coff, int B, void *pack, size_t pack_bytes, float *stage_a, float *stage_d, float *out_scale,
@@ -272,6 +276,9 @@ int gn_conv3d_gcr_split_wino(const float *src, int Cin, const float *a, const fl
                              const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
                              double *out_sum, double *out_sumsq, const unsigned char *tile_active, const float *kconst, int kreach,
                              void *occ_ws, size_t occ_ws_bytes, void *stream);
+int gn_conv3d_gcr_split_wino_partial(const float *src, int Cin, const float *a, const float *d, const void *pack, const float *out_scale,
+                                     const float *act_inv_scale, const float *kbias, int B, int D, int H, int W, int Cout, int relu, float *out,
+                                     double *out_sum, double *out_sumsq, const float *partial, void *stream);
 
 /* The nearest-upsampled source of a decoder convolution in polyphase form (torch.cat((skip, interpolate(x, 'nearest'))) -> Conv3d,
  * components/unet3d.py:291,330): every fine output voxel (2i+pz, 2j+py, 2k+px) sees only a 2 x 2 x 2 block of coarse voxels, so the 27
