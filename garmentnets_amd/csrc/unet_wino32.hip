@@ -14,9 +14,8 @@
 //  * LDS halo: per 16-channel slice and transform position one SLOT of 10 x 10 rows x 4 pairs x 64 B (row pitch 272 B: unet_wino.hip's
 //    conflict-free pitch), FIVE slots rotating exactly as there (slice s+1's position j goes where slice s's j-1 has been multiplied; j = 0: the
 //    spare): 136 000 B.  B ring: a GROUP = the three dy steps of one (j, dz) = 6 KB, FOUR groups deep; the group three ahead is DMA'd right
-//    behind a hand-over (one 1 KB piece per wave: waves 0 - 5 the six pieces, waves 6, 7 repeat pieces 4, 5 -- same bytes to the same place -- so
-//    that every wave's VM queue has the same length and one counted wait serves all).
-//  * staging: thread = (halo row, channel quad): the row's 10 x-consecutive voxels (loaded with asm loads at the end of group 0, invisible to
+//    behind a hand-over by waves 6 and 7 (three 1 KB pieces each), the two waves with next to no halo row to stage.
+//  * staging: thread = (halo row, channel quad): the row's 10 x-consecutive voxels (loaded with asm loads at the start of group 0, invisible to
 //    hipcc's waitcnt pass) -> GroupNorm affine -> four pairs x four transform positions, converted position by position in the groups behind
 //    the one that frees the target slot.  100 rows x 4 quads = 400 of the 512 threads have a row of their own; the others repeat row 99.
 //  * CHAINS of tiles per workgroup and the epilogue without LDS, as unet_wino.hip: the last slice of a tile stages slice 0 of the chain's next
@@ -85,19 +84,35 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino32_kernel(SplitArgs p
 
     f32x16s acc, tot[2];
 
-    // ---- B fragments.  Pack order [slice][step = (j * 3 + dz) * 3 + dy][Cout/32][plane][lane]; a group = three consecutive steps.  Wave w fetches
-    // piece pidx = min(w, w - 2 for w >= 6) of every group: step pidx >> 1, plane pidx & 1 (wave-uniform base in SGPRs + one per-lane offset)
+    // ---- B fragments.  Pack order [slice][step = (j * 3 + dz) * 3 + dy][Cout/32][plane][lane]; a group = three consecutive steps = six 1 KB pieces
+    // (piece i = step i >> 1, plane i & 1).  Waves 6 and 7 -- the two whose threads have (next to) no halo row to stage -- fetch three pieces each;
+    // waves 0 - 5 fetch none: vector-memory results return IN ORDER per wave, so a weight piece issued behind a wave's ten row loads (HBM latency)
+    // cannot land before them -- with the pieces on waves of their own the weight ring never waits for the halo (profiles/r06_ab_experiments.txt)
     const int64_t bstep = (int64_t)ncb * STEPB;
-    const int pidx = wave < 6 ? wave : wave - 2;
-    const int64_t psrc = (int64_t)(pidx >> 1) * bstep + (pidx & 1) * 1024;
-    const unsigned pdst = (unsigned)((pidx >> 1) * STEPB + (pidx & 1) * 1024);
+    const bool dma_wave = wave >= 6;
+    const int pi0 = wave == 7 ? 3 : 0;
     const unsigned char *bgs = nullptr;                                    // (uniform) the weight cursor: start of the group issued next
     const unsigned bvoff = (unsigned)(lane * 16);
 #define W32_ISSUE_GROUP(SLOTI)                                                                                                 \
     do {                                                                                                                       \
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bvoff), "s"(bgs + psrc),             \
-                     "s"(lds_ring + (SLOTI) * GB + pdst) : "memory");                                                          \
+        if (dma_wave) {                                                                                                        \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                                 \
+                const int pi_ = pi0 + i_;                                                                                      \
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(bvoff),                     \
+                             "s"(bgs + (int64_t)(pi_ >> 1) * bstep + (pi_ & 1) * 1024),                                        \
+                             "s"(lds_ring + (SLOTI) * GB + (unsigned)((pi_ >> 1) * STEPB + (pi_ & 1) * 1024)) : "memory");     \
+            }                                                                                                                  \
+        }                                                                                                                      \
         bgs += 3 * bstep;                                                                                                      \
+    } while (0)
+#define W32_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)                 /* lgkmcnt(0) alone */
+    // hand-over waits.  A DMA wave's queue, oldest first: ..., P(g+1) x 3, P(g+2) x 3 (+ its NIT row loads, issued behind P(3) in group 0): all but the
+    // youngest 3 (groups 1, 2: 3 + NIT) must have landed.  A staging wave's queue holds its row loads (and the previous tile's output stores) only:
+    // they must have landed where the conversions start (group 3), nowhere else
+#define W32_HANDOVER_WAIT(G)                                                                                                   \
+    do {                                                                                                                       \
+        if (dma_wave) { if ((G) == 1 || (G) == 2) GN_WAIT_VM_LGKM0(3 + NIT); else GN_WAIT_VM_LGKM0(3); }                        \
+        else { if ((G) == 3) GN_WAIT_VM_LGKM0(0); else W32_WAIT_LGKM0(); }                                                     \
     } while (0)
 
     // ---- staging.  thread = (halo row hz * 10 + hy, channel quad): voxels x0 - 1 .. x0 + 8 of that row -> the row's four pairs.
@@ -269,23 +284,22 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino32_kernel(SplitArgs p
             for (int g = 0; g < 12; ++g) {
                 const int j = g / 3, dz = g % 3, X = g & 1, Y = X ^ 1;
                 // hand-over of group g.  Must have landed: this group's pieces (steps 1, 2 are read right behind the barrier) and the next group's
-                // (its step 0 is read at the end of this group).  VM queue of a wave, oldest first: ..., P(g+1), P(g+2) -- the youngest may stay in
-                // flight; at g == 1 also the NIT row loads issued at the end of group 0, at g == 2 they must have landed (the conversions start).
+                // (its step 0 is read at the end of this group); the row loads where the conversions start (group 3: three groups after their issue).
                 // lgkmcnt(0): the halo stores of the conversion groups are published by the next barrier.  Group 0 of a tile's FIRST slice has had its
                 // hand-over already: behind the prologue's barriers, or at the barrier in front of the previous tile's epilogue.
-                if (g == 1) GN_WAIT_VM_LGKM0(1 + NIT);
-                else if (g > 0 || s > 0) GN_WAIT_VM_LGKM0(1);
+                if (g > 0 || s > 0) W32_HANDOVER_WAIT(g);
                 if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();
                 W32_READ(Y, slo[j], dz * WL::HY + 1, (g % RING) * GB + STEPB);
                 if (g == 9) bgs += wrap;
                 W32_ISSUE_GROUP((g + 3) % RING);                                   // group g + 3 -> the slot group g - 1 vacated
                 // the next slice's conversions, position jn into the slot this slice's jn - 1 has left (jn = 0: the spare), two pairs per group
-                if (g == 2) { affine_load(sn); affine_math(0, NIT); convert(0, nslo[0], 0, 2); }
-                if (g == 3) convert(0, nslo[0], 2, 4);
-                if (g == 4) convert(1, nslo[1], 0, 2);
-                if (g == 5) convert(1, nslo[1], 2, 4);
-                if (g == 6) convert(2, nslo[2], 0, 2);
-                if (g == 7) convert(2, nslo[2], 2, 4);
+                if (g == 0) issue_rows(sn);             // always (uniform wait counts)
+                if (g == 3) { affine_load(sn); affine_math(0, NIT); convert(0, nslo[0], 0, 2); }
+                if (g == 4) convert(0, nslo[0], 2, 4);
+                if (g == 5) convert(1, nslo[1], 0, 2);
+                if (g == 6) convert(1, nslo[1], 2, 4);
+                if (g == 7) convert(2, nslo[2], 0, 2);
+                if (g == 8) convert(2, nslo[2], 2, 4);
                 if (g == 9) convert(3, nslo[3], 0, 2);
                 if (g == 10) convert(3, nslo[3], 2, 4);
                 W32_PROD(X);
@@ -297,14 +311,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino32_kernel(SplitArgs p
                     W32_READ(Y, so, (g1 % 3) * WL::HY, ((g + 1) % RING) * GB);
                 }
                 W32_PROD(X);
-                if (g == 0) issue_rows(sn);             // always (uniform wait counts)
                 if (dz == 2) W32_FLUSH(j);              // this transform position is complete: fold it into the totals, restart the accumulator
             }
             sbase = nbase;
         }
         // the next tile's group-0 hand-over, in front of the epilogue: its groups 0 and 1 have landed (the youngest piece stays in flight), every wave
         // is through with this tile's last ring slot, the last conversions are published
-        GN_WAIT_VM_LGKM0(1);
+        W32_HANDOVER_WAIT(0);
         __builtin_amdgcn_s_barrier();
 
         // ---- epilogue of this tile.  D fragment element q of lane (h, r): pair row i = (q & 3) + 8 (q >> 2) + 4 h = (y = 2 (q >> 2) + h, pair = q & 3),
@@ -388,6 +401,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino32_kernel(SplitArgs p
         item = nitem; b = bn; cb = cbn; z0 = z0n; y0 = y0n; x0 = x0n;
     }
 #undef W32_ISSUE_GROUP
+#undef W32_HANDOVER_WAIT
+#undef W32_WAIT_LGKM0
 #undef W32_READ
 #undef W32_PROD
 #undef W32_FLUSH

@@ -7,7 +7,8 @@ import time
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from garmentnets_amd import ops
 
 DEV = "cuda"
@@ -84,6 +85,32 @@ if __name__ == "__main__":
             check(*cfg)
         check(2, (8, 16, 16), 32, 32, False, with_partial=True)
         check(1, (16, 16, 16), 64, 64, False, with_partial=True)
+    if what == "prof":                     # under rocprofv3 --pmc: one launch of each kernel on the 128 -> 32 layer (zeros and N(0,1)) and the 32 -> 32 layer
+        for B, G, C0, Cout, z in ((16, 128, 128, 32, True),):
+            g = torch.Generator().manual_seed(1)
+            x = (torch.zeros(B, G, G, G, C0) if z else torch.randn(B, G, G, G, C0, generator=g)).to(DEV)
+            w = torch.randn(Cout, C0, 3, 3, 3, generator=g) / (27 * C0) ** 0.5
+            a, d = torch.ones(B, C0, device=DEV), torch.zeros(B, C0, device=DEV)
+            pk, pkd = ops.pack_conv_weight_split_wino(w).to(DEV), ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV)
+            for _ in range(2):
+                ops.conv3d_gcr_split_wino(x, a, d, pk, Cout, with_stats=True)
+                ops.conv3d_gcr_split(x, None, a, d, pkd, Cout, with_stats=True)
+            torch.cuda.synchronize()
+    if what == "w32":                      # the new kernel alone (ablation builds: GARMENTNETS_HIP_LIB=tools/dev/_build/lib_<name>.so)
+        for B, G, C0, Cout, z in ((16, 128, 128, 32, False), (16, 128, 128, 32, True), (16, 128, 32, 32, False), (16, 64, 64, 64, False)):
+            g = torch.Generator().manual_seed(1)
+            x = (torch.zeros(B, G, G, G, C0) if z else torch.randn(B, G, G, G, C0, generator=g)).to(DEV)
+            w = torch.randn(Cout, C0, 3, 3, 3, generator=g) / (27 * C0) ** 0.5
+            a, d, pk = torch.ones(B, C0, device=DEV), torch.zeros(B, C0, device=DEV), ops.pack_conv_weight_split_wino(w).to(DEV)
+            fn = lambda: ops.conv3d_gcr_split_wino(x, a, d, pk, Cout, with_stats=True)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"   B={B} G={G} {C0}->{Cout} {'zeros ' if z else 'N(0,1)'} {ms:8.3f} ms {54.0 * C0 * Cout * B * G ** 3 / ms / 1e9:7.1f} TF-eq", flush=True)
     if what in ("time", "all"):
         timeit(16, 128, 128, 32)
         timeit(16, 128, 128, 32, zeros=True)

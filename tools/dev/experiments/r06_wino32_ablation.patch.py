@@ -1,0 +1,38 @@
+"""timing-only ablations of csrc/unet_wino32.hip (results are WRONG by construction; tools/dev/build_variant.sh <name> this-file with ABL=<which>):
+noconv  the next slice's transform / split / halo stores removed (the halo keeps the prologue's values)
+norows  the row loads removed (and with them the affine)
+nostore the epilogue's output stores and statistics removed
+nodma   the weight DMA of the steady state removed (the ring keeps the prologue's three groups)
+nobar / noread / noflush   the hand-over barrier / the steady state's fragment reads / three of four output transforms removed"""
+import os
+abl = os.environ["ABL"].split(",")
+s = open("unet_wino32.hip").read()
+def rep(a, b):
+    global s
+    assert a in s, a
+    s = s.replace(a, b)
+if "noconv" in abl:
+    for g, j, k in ((3, 0, "0, 2"), (4, 0, "2, 4"), (5, 1, "0, 2"), (6, 1, "2, 4"), (7, 2, "0, 2"), (8, 2, "2, 4"), (9, 3, "0, 2"), (10, 3, "2, 4")):
+        if g == 3:
+            rep("if (g == 3) { affine_load(sn); affine_math(0, NIT); convert(0, nslo[0], 0, 2); }", "")
+        else:
+            rep(f"                if (g == {g}) convert({j}, nslo[{j}], {k});\n", "")
+if "norows" in abl:
+    rep("                if (g == 0) issue_rows(sn);             // always (uniform wait counts)\n", "")
+    rep("if ((G) == 1 || (G) == 2) GN_WAIT_VM_LGKM0(3 + NIT);", "if ((G) == 1 || (G) == 2) GN_WAIT_VM_LGKM0(3);")
+if "nostore" in abl:
+    rep('                    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(vo[q & 3]), "v"(v), "s"(ob) : "memory");\n', '                    asm volatile("" :: "v"(v), "v"(vo[q & 3]), "s"(ob));\n')
+if "nodma" in abl:
+    rep("                W32_ISSUE_GROUP((g + 3) % RING);                                   // group g + 3 -> the slot group g - 1 vacated\n", "")
+if "rowsl2" in abl:      # every tile stages the sample-0 corner tile's rows: the same loads, all of them L2 hits
+    rep("        const int gz = z0_ + hz - 1, gy = y0_ + hy - 1;\n        const bool rowin", "        z0_ = 8; y0_ = 8; x0_ = 8;\n        const int gz = z0_ + hz - 1, gy = y0_ + hy - 1;\n        const bool rowin")
+    rep("            base0 = p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0;", "            base0 = p.src0;")
+if "nobar" in abl:
+    rep("                if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();\n", "")
+if "noread" in abl:      # the fragment reads of the steady state removed (registers keep the prologue's first fragments)
+    rep("                W32_READ(Y, slo[j], dz * WL::HY + 1, (g % RING) * GB + STEPB);\n", "")
+    rep("                W32_READ(X, slo[j], dz * WL::HY + 2, (g % RING) * GB + 2 * STEPB);\n", "")
+    rep("                    W32_READ(Y, so, (g1 % 3) * WL::HY, ((g + 1) % RING) * GB);\n", '')
+if "noflush" in abl:
+    rep("                if (dz == 2) W32_FLUSH(j);", "                if (dz == 2 && j == 3) W32_FLUSH(j);")
+open("unet_wino32.hip", "w").write(s)
