@@ -103,6 +103,9 @@ def parse():
     ap.add_argument("--winograd", default="on", choices=["on", "off"],
                     help="on (default): the 128-wide f16x2 convolutions over one full-resolution source -- above all the first encoder convolution -- in Winograd "
                          "F(2,3) form along x (36 instead of 54 matrix-core tap products per output pair; csrc/unet_wino.hip); off: the direct form everywhere")
+    ap.add_argument("--winograd32", default="on", choices=["on", "off"],
+                    help="on (default): the 32- / 64-wide layers of the two finest levels in the same Winograd form (csrc/unet_wino32.hip, round 6); off: the direct "
+                         "x-strip kernel of rounds 2 - 5")
     ap.add_argument("--decode-mode", default="f16x2", choices=["f16x2", "fp32"], help="arithmetic of the decoder MLPs of the headline pass")
     ap.add_argument("--pipeline-depth", type=int, default=1, choices=[1, 2],
                     help="1 (default): one batch at a time (predict.predict_batch, the reference's loop); 2: every timed pass keeps two batches in "
@@ -519,7 +522,7 @@ def measure_traffic(args):
     import pmc_summary
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--batch", str(args.batch), "--points", str(args.points),
              "--grid", str(args.grid), "--reduce", args.reduce, "--volume-size", str(args.volume_size), "--input", args.input,
-             "--conv-mode", args.conv_mode, "--decode-mode", args.decode_mode]
+             "--conv-mode", args.conv_mode, "--decode-mode", args.decode_mode, "--winograd", args.winograd, "--winograd32", args.winograd32]
     env = dict(os.environ, TMPDIR="/tmp", GARMENTNETS_PREFETCH_ZERO="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -904,7 +907,7 @@ def main():
         timer.install_points()
 
     # the model's arithmetic is a per-model immutable value (garmentnets_amd/arith.py): each pass installs its own
-    headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False, winograd=args.winograd == "on")    # dense, occupancy-independent
+    headline = Arith.named(args.conv_mode, args.decode_mode, sparse_first_conv=False, winograd=args.winograd == "on", winograd32=args.winograd32 == "on")    # dense, occupancy-independent
     model.arith = headline
     auto_level = [False]
 

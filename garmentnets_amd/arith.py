@@ -20,6 +20,9 @@ global mutable state except immutable LUTs).  ``DEFAULT`` is read from the envir
     winograd           (f16x2) the 128-wide convolutions over one full-resolution source -- above all the first encoder convolution, 128 -> 128 at 128^3 --
                        run in Winograd F(2,3) form along x: 36 instead of 54 matrix-core tap products per output pair (csrc/unet_wino.hip); the transforms
                        are exact in the operands' zero pattern, error against fp64 stays within the f16x2 contract (tests/test_gpu_parity.py)
+    winograd32         (f16x2, with winograd) the same form for the 32- / 64-wide layers at the two finest levels -- the encoder's second convolution 128 -> 32 at
+                       128^3, the last decoders' convolutions -- through the 32-wide column-block kernel (csrc/unet_wino32.hip, round 6; the polyphase partial
+                       of a decoder's first convolution is added in its epilogue).  Off: those layers take the direct x-strip kernel (csrc/unet_split.hip)
     polyphase_upconv   polyphase form of the decoders' first convolutions (csrc/upconv.hip)
     fold_final_conv    the decoders absorb the UNet's final 1x1x1 convolution into their first layer (conv_implicit_wnf.UNetResult)
     fused_lattice      lattice queries sampled INSIDE the decoder-MLP kernel (gn_implicit_decode_lattice_split, no sampled-row buffer in
@@ -52,6 +55,7 @@ class Arith:
     sparse_first_conv: bool = True
     affine_in_weights: bool = True
     winograd: bool = True
+    winograd32: bool = True
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
     fused_lattice: bool = False
@@ -76,7 +80,7 @@ class Arith:
         return cls(conv_mode=CONV_MODE_NAMES[_env_choice("GARMENTNETS_CONV_MODE", "f16x2", CONV_MODE_NAMES)],
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
                    sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), affine_in_weights=_env_flag("GARMENTNETS_AFFINE_IN_WEIGHTS"),
-                   winograd=_env_flag("GARMENTNETS_WINOGRAD"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
+                   winograd=_env_flag("GARMENTNETS_WINOGRAD"), winograd32=_env_flag("GARMENTNETS_WINOGRAD32"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
                    fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
 
     def replace(self, **kw):

@@ -23,12 +23,18 @@ def number_of_features_per_level(init_channel_number, num_levels):
 
 
 def _wino_ok(arith, src0, cout):
-    """the layer fits the Winograd form of the 128-wide kernel (arith.winograd; csrc/unet_wino.hip).  Decided from the SAMPLE's shape alone, never
+    """the layer fits a Winograd F(2,3)-along-x kernel (arith.winograd: csrc/unet_wino.hip for Cout % 128 == 0; arith.winograd32: csrc/unet_wino32.hip for the
+    32- / 64-wide layers).  Decided from the SAMPLE's shape alone, never
     from the batch size: the Winograd and the direct form round differently, and a garment's result must not depend on how many garments share its
     batch (the direct kernels may switch variant with the batch size because they are bit-identical to each other)"""
     _, D, H, W, cin = src0.shape
-    return (arith.winograd and arith.conv_mode == ops.SPLIT_F16X2 and ops.wino_supported(cin, cout, (D, H, W))
-            and (D // 4) * (H // 8) * (W // 8) * (cout // 128) >= 32)
+    if not (arith.winograd and arith.conv_mode == ops.SPLIT_F16X2 and ops.wino_supported(cin, cout, (D, H, W))):
+        return False
+    if cout % 128 == 0:
+        return (D // 4) * (H // 8) * (W // 8) * (cout // 128) >= 32
+    # the 32-wide column-block kernel (csrc/unet_wino32.hip, round 6): 8 x 8 x 8 tiles; one workgroup per CU walks chains of tiles -- worth it from a
+    # few tiles per CU and sample on (the 64^3 and 128^3 levels of the UNet)
+    return arith.winograd32 and (D // 8) * (H // 8) * (W // 8) * (cout // 32) >= 512
 
 
 _ACT = {"r": ("ReLU", lambda: nn.ReLU(inplace=True), ops.ACT_RELU), "l": ("LeakyReLU", lambda: nn.LeakyReLU(negative_slope=0.1, inplace=True), ops.ACT_LEAKY),
@@ -194,13 +200,20 @@ class SingleConv(PackedModule, nn.Sequential):
                     return (ops.pack_conv_weight_split(w0, mode).to(dev), ops.pack_upconv_weight(wm, cout, mode).to(dev))
                 pk0, pkm = cache.get(gen, ("poly", mode, c0), build_poly)
                 part = ops.upconv_partial(src1, a[:, c0:].contiguous(), d[:, c0:].contiguous(), pkm, cout, act_inv=act_inv)
+                # the full-resolution part in Winograd form (32- / 64-wide layers: csrc/unet_wino32.hip takes the partial in its epilogue)
+                wino0 = mode == ops.SPLIT_F16X2 and cout % 128 != 0 and _wino_ok(arith, src0, cout)
                 if rest0 is not None and arith.affine_in_weights and mode == ops.SPLIT_F16X2 and c0 % 16 == 0 and cout % 32 == 0:
                     # (a, d carry the sample's power-of-two activation scale: exact to undo)
                     a0 = (a[:, :c0] * act_inv[:, None]).contiguous()
                     d0 = (d[:, :c0] * act_inv[:, None]).contiguous()
                     w0c = cache.get(gen, ("w0", c0), lambda: self.conv.weight.detach()[:, :c0].contiguous())
-                    prep = ops.conv_affine_pack(w0c, a0, d0, st0, rest0)
+                    prep = ops.conv_affine_pack(w0c, a0, d0, st0, rest0, wino=wino0)
                     r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, partial=part)
+                    return r if with_stats else (r, None)
+                if wino0:
+                    pkw = cache.get(gen, ("poly_wino", c0), lambda: ops.pack_conv_weight_split_wino(ops.polyphase_weights(self.conv.weight, c0)[0]).to(self.conv.weight.device))
+                    r = ops.conv3d_gcr_split_wino(src0, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pkw, cout, relu=True, with_stats=with_stats,
+                                                  act_inv=act_inv, partial=part)
                     return r if with_stats else (r, None)
                 r = ops.conv3d_gcr_split(src0, None, a[:, :c0].contiguous(), d[:, :c0].contiguous(), pk0, cout, relu=True, with_stats=with_stats,
                                          act_inv=act_inv, partial=part)

@@ -684,6 +684,93 @@ def test_conv3d_winograd_against_fp64(B, dims, C0, Cout, scattered):
     assert torch.equal(yr, ops.conv3d_gcr_split_persample(s0, prep))
 
 
+@pytest.mark.parametrize("B,dims,C0,Cout,scattered,with_partial", [(2, (8, 16, 16), 32, 32, False, False), (2, (8, 16, 16), 32, 32, True, False),
+                                                                   (1, (8, 8, 8), 128, 32, False, False), (2, (16, 8, 24), 64, 64, False, False),
+                                                                   (1, (16, 16, 16), 128, 32, True, False), (3, (24, 16, 8), 32, 96, False, False), (1, (8, 8, 40), 16, 32, False, False),
+                                                                   (2, (8, 16, 16), 32, 32, False, True), (1, (16, 16, 16), 64, 64, False, True)])
+def test_conv3d_winograd32_against_fp64(B, dims, C0, Cout, scattered, with_partial):
+    """Winograd F(2,3)-along-x form of the 32-wide column-block layers (csrc/unet_wino32.hip through gn_conv3d_gcr_split_wino / _wino_partial; layers:
+    components/unet3d.py:127-144,291,330): both operand forms against torch in fp64, next to the direct x-strip kernel and the fp32-MFMA kernel, with and
+    without the polyphase partial of a decoder's first convolution.  The bar is the f16x2 contract: error <= 2x the fp32-MFMA kernel's.  Volumes of one
+    to three 8 x 8 x 8 tiles per axis: every voxel sits on a face somewhere; chains of tiles cross samples and column blocks."""
+    g = torch.Generator().manual_seed(C0 + Cout + dims[2])
+    D, H, W = dims
+    x = torch.randn(B, C0, D, H, W, generator=g)
+    if scattered:
+        x = x * (torch.rand(B, 1, D, H, W, generator=g) < 0.05)
+    w = torch.randn(Cout, C0, 3, 3, 3, generator=g) / (27 * C0) ** 0.5
+    gamma, beta = torch.rand(C0, generator=g) + 0.5, torch.randn(C0, generator=g)
+    pre = F.conv3d(F.group_norm(x.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1)
+    part = None
+    if with_partial:
+        part = torch.randn(B, D // 2, H // 2, W // 2, 8 * Cout, generator=g)
+        pre = pre + part.double().view(B, D // 2, H // 2, W // 2, 2, 2, 2, Cout).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, Cout, D, H, W)
+        part = part.to(DEV)
+    ref = F.relu(pre)
+    s0 = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    st = ops.channel_stats(s0)
+    a, d, inv = ops.groupnorm_affine(st, None, 8, 1e-5, gamma.to(DEV), beta.to(DEV), with_act_scale=True)
+    a0, d0 = ops.groupnorm_affine(st, None, 8, 1e-5, gamma.to(DEV), beta.to(DEV))
+    cl = lambda t: t.permute(0, 4, 1, 2, 3).cpu().double()
+    err = lambda t: float((cl(t) - ref).abs().max())
+    # the yardstick: the fp32-MFMA kernel (it takes no partial: measured on the same layer without one)
+    ref0 = F.relu(pre) if not with_partial else F.relu(F.conv3d(F.group_norm(x.double(), 8, gamma.double(), beta.double(), eps=1e-5), w.double(), None, padding=1))
+    e32 = float((cl(ops.conv3d_gcr(s0, None, a0, d0, ops.pack_conv_weight(w).to(DEV), Cout)) - ref0).abs().max())
+    e_dir = err(ops.conv3d_gcr_split(s0, None, a, d, ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV), Cout, act_inv=inv, partial=part))
+    pkw = ops.pack_conv_weight_split_wino(w).to(DEV)
+    yw, (sm, sq, V) = ops.conv3d_gcr_split_wino(s0, a, d, pkw, Cout, act_inv=inv, with_stats=True, partial=part)
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    prep = ops.conv_affine_pack(w.to(DEV).contiguous(), a0, d0, st, wino=True)
+    yr, (smr, sqr, _) = ops.conv3d_gcr_split_persample(s0, prep, with_stats=True, partial=part)
+    e_w, e_r = err(yw), err(yr)
+    print(f"B={B} {dims} {C0}->{Cout} {'scattered' if scattered else 'dense'}{' +partial' if with_partial else ''}: err vs fp64: fp32-MFMA {e32:.2e}, x-strip f16x2 {e_dir:.2e}, "
+          f"Winograd-32 literal {e_w:.2e}, affine-in-weights {e_r:.2e}")
+    bar = 2 * max(e32, 2e-6)
+    assert e_w <= bar and e_r <= bar
+    for y, s_, q_ in ((yw, sm, sq), (yr, smr, sqr)):                       # the epilogue statistics are those of the stored values
+        assert float((s_.cpu() - y.double().sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(s_.abs().max()))
+        assert float((q_.cpu() - (y.double() ** 2).sum(dim=(1, 2, 3)).cpu()).abs().max()) <= 1e-9 * max(1.0, float(q_.abs().max()))
+    # run-to-run bit-identity
+    assert torch.equal(yw, ops.conv3d_gcr_split_wino(s0, a, d, pkw, Cout, act_inv=inv, partial=part))
+    assert torch.equal(yr, ops.conv3d_gcr_split_persample(s0, prep, partial=part))
+
+
+def test_conv3d_winograd32_shape_contract_and_occupancy_aware_launch():
+    """(1) shapes outside the 32-wide Winograd kernel's contract are refused with GN_EINVAL (ValueError), never run; (2) its occupancy-aware launch (active
+    list at the kernel's 8 x 8 x 8 granularity + border-class constants from its own dense launch over the 8^3 at-rest volume) is bit-identical to its
+    dense launch, through SingleConv.run behind a scattered volume (reach 1)"""
+    from garmentnets_amd.components.unet3d import SingleConv
+    w = torch.randn(32, 32, 3, 3, 3)
+    pk = ops.pack_conv_weight_split_wino(w).to(DEV)
+    ones = lambda B, C: (torch.ones(B, C, device=DEV), torch.zeros(B, C, device=DEV))
+    for dims, cin in (((12, 8, 8), 32), ((8, 8, 12), 32)):                   # not whole 8 x 8 x 8 tiles
+        with pytest.raises(ValueError):
+            ops.conv3d_gcr_split_wino(torch.zeros(1, *dims, cin, device=DEV), *ones(1, cin), pk, 32)
+    with pytest.raises(ValueError):                                           # a partial goes with the 32-wide kernel only
+        ops.conv3d_gcr_split_wino(torch.zeros(1, 8, 8, 8, 32, device=DEV), *ones(1, 32), ops.pack_conv_weight_split_wino(torch.randn(128, 32, 3, 3, 3)).to(DEV), 128,
+                                  partial=torch.zeros(1, 4, 4, 4, 8 * 128, device=DEV))
+    g = torch.Generator().manual_seed(22)
+    B, G, C = 3, 64, 32
+    conv = SingleConv(C, 32).to(DEV)
+    conv.load_state_dict({k: S.synthetic_tensor("w32." + k, tuple(v.shape), 4).to(DEV) for k, v in conv.state_dict().items()})
+    x = torch.zeros(B, G, G, G, C)
+    n = 60
+    idx = torch.randint(0, G, (B - 1, n, 3), generator=g)
+    for b in range(B - 1):
+        x[b, idx[b, :, 0], idx[b, :, 1], idx[b, :, 2]] = torch.randn(n, C, generator=g).abs() * 2.0
+    flat = torch.cat([((b * G + idx[b, :, 0]) * G + idx[b, :, 1]) * G + idx[b, :, 2] for b in range(B - 1)]).to(torch.int32).to(DEV)
+    xg = x.to(DEV)
+    ar = AR.DEFAULT.replace(conv_mode=AR.SPLIT_F16X2, affine_in_weights=True, winograd=True, winograd32=True)
+    y_d, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False))
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    y_s, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=True))
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    assert torch.equal(y_s, y_d) and bool(torch.isfinite(y_d).all()) and float(y_d.abs().max()) > 0
+    y_strip, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False, winograd32=False))
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_strip_kernel<true>"
+    assert float((y_strip - y_d).abs().max()) <= 2e-5 * max(1.0, float(y_d.abs().max()))       # two fp32-class roundings of the same layer
+
+
 def test_conv3d_winograd_occupancy_aware_launch_and_shape_contract():
     """(1) the occupancy-aware launch of the Winograd kernel (active-tile list + border-class constants from the DIRECT form's 5^3 launch: away from
     the cells the operand is exactly zero in either form) is bit-identical to its dense launch; (2) shapes outside the kernel's contract are
@@ -715,7 +802,9 @@ def test_conv3d_winograd_occupancy_aware_launch_and_shape_contract():
         s0 = torch.randn(1, *dims, 32, generator=g).to(DEV)
         with pytest.raises(ValueError):
             ops.conv3d_gcr_split_wino(s0, torch.ones(1, 32, device=DEV), torch.zeros(1, 32, device=DEV), pk, 128)
-    assert not ops.wino_supported(32, 64, (8, 8, 8)) and not ops.wino_supported(272, 128, (8, 8, 8)) and ops.wino_supported(256, 256, (4, 8, 8))
+    # (Cout = 64: the 32-wide column-block kernel of round 6 -- whole 8 x 8 x 8 tiles, Cin <= 128)
+    assert ops.wino_supported(32, 64, (8, 8, 8)) and not ops.wino_supported(32, 64, (4, 8, 8)) and not ops.wino_supported(144, 64, (8, 8, 8))
+    assert not ops.wino_supported(272, 128, (8, 8, 8)) and ops.wino_supported(256, 256, (4, 8, 8)) and not ops.wino_supported(32, 48, (8, 8, 8))
 
 
 def test_conv3d_winograd_chain_length_does_not_change_a_bit(monkeypatch):

@@ -27,6 +27,12 @@ if "nodma" in abl:
 if "rowsl2" in abl:      # every tile stages the sample-0 corner tile's rows: the same loads, all of them L2 hits
     rep("        const int gz = z0_ + hz - 1, gy = y0_ + hy - 1;\n        const bool rowin", "        z0_ = 8; y0_ = 8; x0_ = 8;\n        const int gz = z0_ + hz - 1, gy = y0_ + hy - 1;\n        const bool rowin")
     rep("            base0 = p.src0 + (int64_t)b * p.D * p.H * p.W * p.C0;", "            base0 = p.src0;")
+if "samehalf" in abl:    # odd slices re-read the even slice's 64 bytes of every voxel: does the L2 keep a line from one slice to the next?
+    rep("const unsigned cb4 = (unsigned)sl * (SP_KS * 4u), vs", "const unsigned cb4 = (unsigned)(sl & ~1) * (SP_KS * 4u), vs")
+if "contig" in abl:      # the loads of a channel-BLOCKED input [slice][z][y][x][16]: same count, same rows, contiguous 64-byte pieces along x
+    rep("const unsigned cb4 = (unsigned)sl * (SP_KS * 4u), vs = (unsigned)p.C0 * 4u;", "const unsigned vs = 64u, cb4 = (unsigned)sl * (unsigned)(p.D * p.H * p.W) * 64u;")
+    rep("        const unsigned vs = (unsigned)p.C0 * 4u;\n        voff1 = rowin ? ((unsigned)((gz * p.H + gy) * p.W + x0_) * (unsigned)p.C0 + (unsigned)cq) * 4u : (unsigned)cq * 4u;",
+        "        const unsigned vs = 64u;\n        voff1 = rowin ? ((unsigned)((gz * p.H + gy) * p.W + x0_) * 16u + (unsigned)cq) * 4u : (unsigned)cq * 4u;")
 if "nobar" in abl:
     rep("                if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();\n", "")
 if "noread" in abl:      # the fragment reads of the steady state removed (registers keep the prologue's first fragments)
