@@ -33,6 +33,16 @@ if "contig" in abl:      # the loads of a channel-BLOCKED input [slice][z][y][x]
     rep("const unsigned cb4 = (unsigned)sl * (SP_KS * 4u), vs = (unsigned)p.C0 * 4u;", "const unsigned vs = 64u, cb4 = (unsigned)sl * (unsigned)(p.D * p.H * p.W) * 64u;")
     rep("        const unsigned vs = (unsigned)p.C0 * 4u;\n        voff1 = rowin ? ((unsigned)((gz * p.H + gy) * p.W + x0_) * (unsigned)p.C0 + (unsigned)cq) * 4u : (unsigned)cq * 4u;",
         "        const unsigned vs = 64u;\n        voff1 = rowin ? ((unsigned)((gz * p.H + gy) * p.W + x0_) * 16u + (unsigned)cq) * 4u : (unsigned)cq * 4u;")
+for hint in ("nt", "sc1", "sc0 sc1 nt"):     # cache-policy hints on the row loads (real variants: results stay correct)
+    if "rows_" + hint.replace(" ", "_") in abl:
+        rep('asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[k])', 'asm volatile("global_load_dwordx4 %0, %1, %2 ' + hint + '" : "=v"(raw[k])')
+if "acc2" in abl:        # a REAL variant: the cross products (1,0), (0,1) and the main product (0,0) in accumulators of their own (no MFMA waits for the one before it)
+    import re
+    rep("    f32x16s acc, tot[2];", "    f32x16s acc, acch, tot[2];")
+    s, n1 = re.subn(r"acc = mfma16<F16>\(fa\[SET\]\[0\], fb\[SET\]\[0\], acc\);  ", "acch = mfma16<F16>(fa[SET][0], fb[SET][0], acch);", s)
+    s, n2 = re.subn(r"const float m = acc\[q\];                                     ", "const float m = __fadd_rn(acc[q], acch[q]); acch[q] = 0.f;", s)
+    assert n1 == 1 and n2 == 1, (n1, n2)
+    rep("        for (int q = 0; q < 16; ++q) { acc[q] = 0.f; tot[0][q] = 0.f; tot[1][q] = 0.f; }", "        for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acch[q] = 0.f; tot[0][q] = 0.f; tot[1][q] = 0.f; }")
 if "nobar" in abl:
     rep("                if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();\n", "")
 if "noread" in abl:      # the fragment reads of the steady state removed (registers keep the prologue's first fragments)
