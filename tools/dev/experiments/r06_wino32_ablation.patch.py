@@ -43,6 +43,15 @@ if "acc2" in abl:        # a REAL variant: the cross products (1,0), (0,1) and t
     s, n2 = re.subn(r"const float m = acc\[q\];                                     ", "const float m = __fadd_rn(acc[q], acch[q]); acch[q] = 0.f;", s)
     assert n1 == 1 and n2 == 1, (n1, n2)
     rep("        for (int q = 0; q < 16; ++q) { acc[q] = 0.f; tot[0][q] = 0.f; tot[1][q] = 0.f; }", "        for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acch[q] = 0.f; tot[0][q] = 0.f; tot[1][q] = 0.f; }")
+if "pairload" in abl:    # timing-only: both 64-byte halves of every 128-byte line requested together, every second slice (the other slice requests nothing)
+    rep("    f32x4m raw[NIT];", "    f32x4m raw[NIT], rawd[NIT];")
+    rep("""            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[k]) : "v"(vo), "s"(base0) : "memory");""",
+        """            if ((sl & 1) == 0) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[k]) : "v"(vo), "s"(base0) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(rawd[k]) : "v"(vo), "s"(base0) : "memory");
+            }""")
+    rep("                if (g == 3) { affine_load(sn);", "                if (g == 3) { _Pragma(\"unroll\") for (int k_ = 0; k_ < NIT; ++k_) asm volatile(\"\" :: \"v\"(rawd[k_])); affine_load(sn);")
+    rep("if (dma_wave) { if ((G) == 1 || (G) == 2) GN_WAIT_VM_LGKM0(3 + NIT); else GN_WAIT_VM_LGKM0(3); }", "if (dma_wave) GN_WAIT_VM_LGKM0(3);")
 if "nobar" in abl:
     rep("                if (g > 0 || s > 0) __builtin_amdgcn_s_barrier();\n", "")
 if "noread" in abl:      # the fragment reads of the steady state removed (registers keep the prologue's first fragments)
