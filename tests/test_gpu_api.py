@@ -633,7 +633,15 @@ def _two_rank_bench(backend):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints, rank 1 does not
-    line = json.loads(lines[0])
+    compact = json.loads(lines[0])
+    assert len(lines[0]) < bench.COMPACT_LIMIT and tuple(compact) == bench.COMPACT_KEYS          # the stdout contract (tests/test_bench_line.py)
+    assert compact["n_gpus"] == 2 and compact["rccl_ranks_seen"] == 2 and compact["dist_backend"] == backend and compact["roofline"]["kernel"]
+    assert len(compact["per_rank"]["garments_per_s"]) == 2 and compact["per_rank"]["slowest_over_fastest"] >= 1.0
+    # everything else travels in the detail dict: rank 0's stderr (and the file the line names)
+    det = [l for l in out.stderr.splitlines() if l.startswith("[bench detail] ")]
+    assert len(det) == 1
+    line = json.loads(det[0][len("[bench detail] "):])
+    assert line["value"] == pytest.approx(compact["value"], rel=1e-5)
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["dist_backend"] == backend
     assert len(line["per_rank"]["seconds"]) == 2 and all(t > 0 for t in line["per_rank"]["seconds"]) and line["per_rank"]["slowest_over_fastest"] >= 1.0
     assert line["per_rank"]["host_affinity_rank0"]["pinned"], line["per_rank"]

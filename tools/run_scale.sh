@@ -28,11 +28,14 @@ for N in 1 2 4 8; do
     echo "$LINE" >> "$OUT/scale.jsonl"
     CUR="$REPO/profiles/${TAG}_scale_n${N}.json"
     echo "$LINE" > "$CUR"
+    # the per-garment checksums and the per-rank seconds live in the detail file bench.py names in the line (round 6: the stdout line is compact)
+    DET="$REPO/profiles/${TAG}_scale_n${N}_detail.json"
+    cp "$REPO/gpurun_out/bench_detail.json" "$DET"
     V=$(python -c "import json,sys; print(json.load(open(sys.argv[1]))['value'])" "$CUR" 2>/dev/null) || V=""
     [ "$N" -eq 1 ] && N1=$V
     echo "N=$N value=$V garments/s  (n1=$N1)"
     if [ -n "$PREV" ]; then
-        python - "$PREV" "$CUR" <<'PY' || RC=1
+        python - "$PREVDET" "$DET" <<'PY' || RC=1
 import json, sys
 a, b = (json.load(open(p)) for p in sys.argv[1:3])
 ca, cb = a["garment_checksums"], b["garment_checksums"]
@@ -41,6 +44,6 @@ print(f"   garment checksums: the first {len(ca)} of N={b['n_gpus']} {'==' if ok
 sys.exit(0 if ok else 1)
 PY
     fi
-    PREV=$CUR
+    PREV=$CUR; PREVDET=$DET
 done
 exit $RC
