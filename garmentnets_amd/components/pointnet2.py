@@ -126,7 +126,7 @@ class SAModule(torch.nn.Module):
         # is a prefix (include/garmentnets_hip.h gn_fps_nested; decided per example on the device from the first level's smallest running maximum)
         gap = nested = None
         if start is None and seg.num > 0:
-            gap = torch.empty(seg.num, dtype=torch.float32, device=pos.device)
+            gap = torch.zeros(seg.num, dtype=torch.float32, device=pos.device)      # (0 = "not nested": an example the kernel returns from early leaves it)
             src = getattr(pos, "_fps_cascade", None)
             if src is not None and src[1] == seg.sizes and src[2] == pos._version and src[0].device == pos.device:
                 nested = src[0]

@@ -245,15 +245,17 @@ class SingleConv(PackedModule, nn.Sequential):
         sp = {}
         small_in = sparse.get("small_in")
         if (arith.sparse_first_conv and src0.shape[-1] <= 384 and (cout % 128 == 0 or cout % 64 != 0) and min(src0.shape[1:4]) > 2 * reach
-                and (reach == 1 or small_in is not None)):
+                and (reach == 1 or small_in is not None)
+                # (the class constants must come from the kernel -- and the pack -- the real launch takes: a Winograd layer handed a small volume it cannot
+                #  take, 5^3 from a layer that ran in the direct form, simply runs dense, as in run().  At reach 2 the small volume holds the previous
+                #  layer's face values, the operand is NOT zero there and the two forms round differently: constants from the direct pack would break
+                #  "occupancy-aware == dense, bit for bit" for such mixed configurations)
+                and (not wino or small_in is None or ops.wino_supported(src0.shape[-1], cout, small_in.shape[1:4]))):
             if small_in is None:
-                n = 8 if wino else 5              # the Winograd kernel takes whole 4 x 8 x 8 tiles
+                n = 8 if wino else 5              # the Winograd kernels take whole tiles (4 x 8 x 8 / 8 x 8 x 8)
                 small_in = torch.zeros((B, n, n, n, src0.shape[-1]), dtype=torch.float32, device=src0.device)
-            # a plain dense launch over the small all-at-rest volume.  (A Winograd pack cannot serve a 5^3 volume handed down by a layer that ran in
-            # the direct form: the constants then come from the direct form's pack -- away from the cells the operand is exactly zero in either
-            # form, so they are the same numbers)
-            small_prep = prep if (not wino or ops.wino_supported(src0.shape[-1], cout, small_in.shape[1:4])) else ops.conv_affine_pack(w, a, d, st0, rest)
-            small_out = ops.conv3d_gcr_split_persample(small_in, small_prep, relu=True)
+            # a plain dense launch of the same kernel with the same pack over the small all-at-rest volume
+            small_out = ops.conv3d_gcr_split_persample(small_in, prep, relu=True)
             sp = dict(tile_active=ops.grid_tile_flags(sparse["flat"], B, src0.shape[1:4], reach), kconst=_class_constants(small_out, reach, cout), kreach=reach)
             sparse["small_out"] = small_out
         r = ops.conv3d_gcr_split_persample(src0, prep, relu=True, with_stats=with_stats, **sp)

@@ -8,6 +8,16 @@
 
 #define GN_WAVE 64
 
+// This library is written for ONE target: gfx950 (MI355X, CDNA4) with the ROCm 7 toolchain (clang >= 20).  The kernels use its instructions directly
+// (v_mfma_f32_32x32x16_f16, global_load_lds_dwordx4, v_fma_mix_f32, v_maximum3_f32 through __builtin_elementwise_maximum) and there is no other code
+// path: the Makefile's HIPCC / ARCH overrides exist for a differently installed ROCm, not for another architecture -- say so at compile time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgarmentnets_hip.so is gfx950-only (MI355X): build with --offload-arch=gfx950"
+#endif
+#if !defined(__has_builtin) || !__has_builtin(__builtin_elementwise_maximum)
+#error "libgarmentnets_hip.so needs the ROCm 7 hipcc (clang >= 20: __builtin_elementwise_maximum)"
+#endif
+
 void gn_set_error(const char *fmt, ...);
 
 #define GN_REQUIRE(cond, ...)            \

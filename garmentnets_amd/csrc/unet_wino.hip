@@ -474,12 +474,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino_kernel(SplitArgs p) 
 // (called by conv3d_gcr_split_impl, unet_split.hip, which owns the shape checks and the occupancy-aware list / fill launches)
 void gn_launch_conv3d_wino(const SplitArgs &p0, int tiles, hipStream_t st) {
     SplitArgs p = p0;
-    // chain length: 16 tiles hide 15 of 16 prologues / epilogues; shorter when that would leave fewer than ~4 chains per CU (load balance is
-    // the dispatcher's: chains are its unit).  GARMENTNETS_WINO_CHAIN overrides (tests and measurements: results do not depend on it)
-    const int64_t items = (int64_t)tiles * (p.Cout / 128) * p.B;              // (occupancy-aware: the dense bound; chains past the list's end return)
-    int chain = (int)(items / (32 * 32));
+    // chain length: 16 tiles hide 15 of 16 prologues / epilogues; shorter when that would leave fewer than ~4 chains per CU and sample.  From the SAMPLE's
+    // tiles alone, never the batch size: the chain is the unit in which the fp64 epilogue statistics are grouped, and a garment's GroupNorm statistics
+    // must not depend (not even in the last bit) on how many garments share its batch.  GARMENTNETS_WINO_CHAIN overrides (tests and
+    // measurements: the outputs do not depend on it)
+    const int64_t per_sample = (int64_t)tiles * (p.Cout / 128);
+    int chain = (int)(per_sample / 64);
     chain = chain < 1 ? 1 : chain > 16 ? 16 : chain;
+    // (looked up per launch, ~100 ns against a multi-millisecond kernel: tests/test_gpu_parity.py varies it inside one process)
     if (const char *e = getenv("GARMENTNETS_WINO_CHAIN")) { const int forced = atoi(e); if (forced > 0 && forced <= 4096) chain = forced; }
+    const int64_t items = per_sample * p.B;                                    // (occupancy-aware: the dense bound; chains past the list's end return)
     p.chain = chain;
     const int64_t span = 32 * (int64_t)chain;
     hipLaunchKernelGGL((conv3d_split_wino_kernel<true>), dim3((unsigned)((items + span - 1) / span * 32)), dim3(512), 0, st, p);

@@ -416,8 +416,8 @@ void gn_launch_conv3d_wino32(const SplitArgs &p0, int tiles8, hipStream_t st) {
     const int64_t per_sample = (int64_t)tiles8 * (p.Cout / 32);
     int chain = (int)(per_sample / 64);
     chain = chain < 1 ? 1 : chain > 16 ? 16 : chain;
-    static const int forced = [] { const char *e = getenv("GARMENTNETS_WINO_CHAIN"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 4096 ? v : 0; }();
-    if (forced) chain = forced;
+    // (looked up per launch, ~100 ns against a multi-millisecond kernel: tests/test_gpu_parity.py varies it inside one process)
+    if (const char *e = getenv("GARMENTNETS_WINO_CHAIN")) { const int forced = atoi(e); if (forced > 0 && forced <= 4096) chain = forced; }
     p.chain = chain;
     const int64_t items = per_sample * p.B;                                    // (occupancy-aware: the dense bound; chains past the list's end return)
     const int64_t span = 32 * (int64_t)chain;

@@ -816,7 +816,8 @@ def test_conv3d_winograd_chain_length_does_not_change_a_bit(monkeypatch):
     from garmentnets_amd.components.unet3d import SingleConv
     g = torch.Generator().manual_seed(77)
     cases = []
-    for (B, D, H, W, C, Cout) in ((3, 16, 32, 32, 32, 128), (2, 8, 24, 40, 64, 256)):
+    # (Cout = 32 / 64: the 32-wide column-block kernel of round 6, csrc/unet_wino32.hip -- the same chain machinery at its 8 x 8 x 8 tile granularity)
+    for (B, D, H, W, C, Cout) in ((3, 16, 32, 32, 32, 128), (2, 8, 24, 40, 64, 256), (3, 16, 32, 32, 32, 32), (2, 8, 24, 40, 64, 64)):
         x = torch.randn(B, D, H, W, C, generator=g).to(DEV)
         w = torch.randn(Cout, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
         gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
