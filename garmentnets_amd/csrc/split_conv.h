@@ -128,4 +128,5 @@ __device__ __forceinline__ f32x16s mfma16(const uint4 &a, const uint4 &b, const 
 // unet_wino.hip: launch of conv3d_split_wino_kernel<true> over `tiles` 4 x 8 x 8 tiles per sample (shape checks: conv3d_gcr_split_impl)
 void gn_launch_conv3d_wino(const SplitArgs &p, int tiles, hipStream_t st);
 // unet_wino32.hip: launch of conv3d_split_wino32_kernel<true> over `tiles8` 8 x 8 x 8 tiles per sample x Cout / 32 column blocks
-void gn_launch_conv3d_wino32(const SplitArgs &p, int tiles8, hipStream_t st);
+bool gn_launch_conv3d_wino32(const SplitArgs &p, int tiles8, hipStream_t st);
+void gn_launch_conv3d_wino32pc(const SplitArgs &p, unsigned grid, hipStream_t st);      // unet_wino32pc.hip (p.chain set by the caller)

@@ -1065,8 +1065,8 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
         p.active_count = count;
     }
     if (wino32) {
-        gn_launch_conv3d_wino32(p, tiles8, st);
-        gn_note_kernel("conv3d_split_wino32_kernel<true>");
+        const bool pc = gn_launch_conv3d_wino32(p, tiles8, st);
+        gn_note_kernel(pc ? "conv3d_split_wino32pc_kernel<true>" : "conv3d_split_wino32_kernel<true>");
     } else if (wino) {
         gn_launch_conv3d_wino(p, tiles, st);
         gn_note_kernel("conv3d_split_wino_kernel<true>");

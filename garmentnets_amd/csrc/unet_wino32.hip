@@ -410,7 +410,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_split_wino32_kernel(SplitArgs p
 }
 
 // (called by conv3d_gcr_split_impl, unet_split.hip, which owns the shape checks and the occupancy-aware list / fill launches)
-void gn_launch_conv3d_wino32(const SplitArgs &p0, int tiles8, hipStream_t st) {
+// -> true: the wave-specialised kernel (unet_wino32pc.hip) was launched
+bool gn_launch_conv3d_wino32(const SplitArgs &p0, int tiles8, hipStream_t st) {
     SplitArgs p = p0;
     // chain length from the SAMPLE's tiles only (not the batch size): a sample's statistics are then reduced in the same order whatever the batch
     const int64_t per_sample = (int64_t)tiles8 * (p.Cout / 32);
@@ -421,5 +422,13 @@ void gn_launch_conv3d_wino32(const SplitArgs &p0, int tiles8, hipStream_t st) {
     p.chain = chain;
     const int64_t items = per_sample * p.B;                                    // (occupancy-aware: the dense bound; chains past the list's end return)
     const int64_t span = 32 * (int64_t)chain;
-    hipLaunchKernelGGL((conv3d_split_wino32_kernel<true>), dim3((unsigned)((items + span - 1) / span * 32)), dim3(512), 0, st, p);
+    const unsigned grid = (unsigned)((items + span - 1) / span * 32);
+    // DEFAULT: the wave-specialised form of the same tile (unet_wino32pc.hip: waves 0 - 3 multiply two z-slices each, waves 4 - 7 stage and fetch) -- bit-identical
+    // results, 2.5 - 3.7 % faster in the bench step (profiles/r06_ab_experiments.txt section 6).  GARMENTNETS_WINO32_PC=0 selects this file's kernel (every wave one
+    // z-slice and a share of the staging): the form sections 1 - 4 of that record measured; tests/test_gpu_parity.py runs both and compares them bit for bit
+    bool pc = true;
+    if (const char *e = getenv("GARMENTNETS_WINO32_PC")) pc = atoi(e) != 0;
+    if (pc) { gn_launch_conv3d_wino32pc(p, grid, st); return true; }
+    hipLaunchKernelGGL((conv3d_split_wino32_kernel<true>), dim3(grid), dim3(512), 0, st, p);
+    return false;
 }

@@ -719,7 +719,7 @@ def test_conv3d_winograd32_against_fp64(B, dims, C0, Cout, scattered, with_parti
     e_dir = err(ops.conv3d_gcr_split(s0, None, a, d, ops.pack_conv_weight_split(w, ops.SPLIT_F16X2).to(DEV), Cout, act_inv=inv, partial=part))
     pkw = ops.pack_conv_weight_split_wino(w).to(DEV)
     yw, (sm, sq, V) = ops.conv3d_gcr_split_wino(s0, a, d, pkw, Cout, act_inv=inv, with_stats=True, partial=part)
-    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32pc_kernel<true>"
     prep = ops.conv_affine_pack(w.to(DEV).contiguous(), a0, d0, st, wino=True)
     yr, (smr, sqr, _) = ops.conv3d_gcr_split_persample(s0, prep, with_stats=True, partial=part)
     e_w, e_r = err(yw), err(yr)
@@ -733,6 +733,36 @@ def test_conv3d_winograd32_against_fp64(B, dims, C0, Cout, scattered, with_parti
     # run-to-run bit-identity
     assert torch.equal(yw, ops.conv3d_gcr_split_wino(s0, a, d, pkw, Cout, act_inv=inv, partial=part))
     assert torch.equal(yr, ops.conv3d_gcr_split_persample(s0, prep, partial=part))
+
+
+def test_conv3d_winograd32_wave_specialised_kernel_is_bit_identical_to_the_plain_one(monkeypatch):
+    """the default launch of the 32-wide Winograd layers is the wave-specialised kernel (csrc/unet_wino32pc.hip: four waves multiply two z-slices each, four stage the
+    halo and fetch the weights); GARMENTNETS_WINO32_PC=0 selects the kernel every wave of which does both (csrc/unet_wino32.hip).  Same tile, same products in the same
+    order per output: bit-identical outputs -- literal pack, per-sample packs, with the polyphase partial, chains crossing samples and column blocks; statistics equal
+    to fp64 rounding (merged by fp64 atomics in hardware order)"""
+    g = torch.Generator().manual_seed(5)
+    for (B, D, H, W, C, Cout, with_partial) in ((3, 16, 24, 32, 64, 64, True), (2, 8, 16, 16, 128, 32, False), (2, 24, 8, 8, 32, 96, False)):
+        x = torch.randn(B, D, H, W, C, generator=g).to(DEV)
+        w = torch.randn(Cout, C, 3, 3, 3, generator=g) / (27 * C) ** 0.5
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+        st = ops.channel_stats(x)
+        a, d, inv = ops.groupnorm_affine(st, None, 8, 1e-5, gamma, beta, with_act_scale=True)
+        a0, d0 = ops.groupnorm_affine(st, None, 8, 1e-5, gamma, beta)
+        pk = ops.pack_conv_weight_split_wino(w).to(DEV)
+        prep = ops.conv_affine_pack(w.to(DEV).contiguous(), a0, d0, st, wino=True)
+        part = torch.randn(B, D // 2, H // 2, W // 2, 8 * Cout, generator=g).to(DEV) if with_partial else None
+        res = {}
+        for pc, name in (("1", "conv3d_split_wino32pc_kernel<true>"), ("0", "conv3d_split_wino32_kernel<true>")):
+            monkeypatch.setenv("GARMENTNETS_WINO32_PC", pc)
+            yl, stl_ = ops.conv3d_gcr_split_wino(x, a, d, pk, Cout, act_inv=inv, with_stats=True, partial=part)
+            assert ops._lib.load().gn_last_kernel().decode() == name
+            yr, str_ = ops.conv3d_gcr_split_persample(x, prep, with_stats=True, partial=part)
+            res[pc] = (yl, stl_, yr, str_)
+        monkeypatch.delenv("GARMENTNETS_WINO32_PC")
+        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][2], res["0"][2])
+        for i in (1, 3):
+            for s1, s0 in zip(res["1"][i][:2], res["0"][i][:2]):
+                assert float((s1 - s0).abs().max()) <= 1e-12 * max(1.0, float(s0.abs().max()))
 
 
 def test_conv3d_winograd32_shape_contract_and_occupancy_aware_launch():
@@ -762,9 +792,9 @@ def test_conv3d_winograd32_shape_contract_and_occupancy_aware_launch():
     xg = x.to(DEV)
     ar = AR.DEFAULT.replace(conv_mode=AR.SPLIT_F16X2, affine_in_weights=True, winograd=True, winograd32=True)
     y_d, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False))
-    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32pc_kernel<true>"
     y_s, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=True))
-    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32_kernel<true>"
+    assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_wino32pc_kernel<true>"
     assert torch.equal(y_s, y_d) and bool(torch.isfinite(y_d).all()) and float(y_d.abs().max()) > 0
     y_strip, _ = conv.run(xg, None, sparse=dict(flat=flat, reach=1), arith=ar.replace(sparse_first_conv=False, winograd32=False))
     assert ops._lib.load().gn_last_kernel().decode() == "conv3d_split_strip_kernel<true>"

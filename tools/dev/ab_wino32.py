@@ -81,7 +81,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("check", "all"):
         for cfg in [(2, (8, 16, 16), 32, 32, False), (2, (8, 16, 16), 32, 32, True), (1, (8, 8, 8), 128, 32, False), (2, (16, 8, 24), 64, 64, False),
-                    (1, (16, 16, 16), 128, 32, True), (1, (8, 8, 40), 48, 32, False), (3, (24, 16, 8), 32, 96, False)]:
+                    (1, (16, 16, 16), 128, 32, True), (1, (8, 8, 40), 16, 32, False), (3, (24, 16, 8), 32, 96, False)]:
             check(*cfg)
         check(2, (8, 16, 16), 32, 32, False, with_partial=True)
         check(1, (16, 16, 16), 64, 64, False, with_partial=True)

@@ -23,7 +23,7 @@ def load(path):
 # default 2.0; the split-operand kernels read their halos exactly like the fp32 kernels (64-byte pieces at a channel stride)
 # conv3d_split_wino_kernel: calibrated in round 5 (tools/dev/calib_wino_fetch.sh, profiles/r05_ab_experiments.txt section 5): 1.24
 # conv3d_split_wino32_kernel (round 6): the x-strip kernel's access pattern (64-byte pieces of a 10 x 10 x 10 halo at a channel stride): its factor, not calibrated separately
-FETCH_FACTOR = {"conv3d_split_wino_kernel<true>": 1.24, "conv3d_split_wino32_kernel<true>": 1.42, "conv3d_gcr_kernel<2>": 1.26, "conv3d_gcr_kernel<1>": 1.42,
+FETCH_FACTOR = {"conv3d_split_wino_kernel<true>": 1.24, "conv3d_split_wino32_kernel<true>": 1.42, "conv3d_split_wino32pc_kernel<true>": 1.42, "conv3d_gcr_kernel<2>": 1.26, "conv3d_gcr_kernel<1>": 1.42,
                 "conv3d_split_wide_kernel<2, true>": 1.26, "conv3d_split_wide_kernel<2, false>": 1.26,
                 "conv3d_split_strip_kernel<true>": 1.42, "conv3d_split_strip_kernel<false>": 1.42,      # the halo reads of conv3d_split_kernel<1>
                 "conv3d_split_kernel<1, 2, true, 1>": 1.42, "conv3d_split_kernel<2, 2, true, 1>": 1.42,
