@@ -224,13 +224,76 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float *__restrict__ 
     if (gap_out && tid == 0) gap_out[b] = gmin;
 }
 
+// Large examples (more points than the register-resident kernel's 16 per lane x 1024 lanes): the running distances live in LDS (one float per point, up to
+// FPS_LDS_MAX points = 144 KB), the coordinates are re-read from global memory every step (L2-resident).  Same arithmetic, same tie rule (a thread walks its
+// points in ascending index and keeps the first maximum; wave and workgroup reductions as above), so the index lists are the oracle's for any size; the price is
+// ~n / 1024 dependent LDS round trips per step instead of a register update -- a correctness path for clouds the reference's fps (no limit,
+// components/pointnet2.py:26) would take, not a tuned one.
+#define FPS_LDS_MAX (36 * 1024)
+__global__ __launch_bounds__(FPS_THREADS) void fps_lds_kernel(const float *__restrict__ pos, const int32_t *__restrict__ ptr, const int32_t *__restrict__ out_ptr,
+                                                             const int32_t *__restrict__ start_idx, int32_t *__restrict__ out_idx, float *__restrict__ gap_out,
+                                                             const float *__restrict__ nested_gap) {
+    constexpr int WAVES = FPS_WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int s = ptr[b], n = ptr[b + 1] - s;
+    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
+    if (n <= 0 || m <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (nested_gap && nested_gap[b] > 0.f && m <= n) {
+        for (int k = tid; k < m; k += FPS_THREADS) out_idx[o0 + k] = s + k;
+        if (gap_out && tid == 0) gap_out[b] = nested_gap[b];
+        return;
+    }
+    float *pv = smem;
+    int *pi = (int *)(smem + 2 * WAVES);
+    float *dd = smem + 4 * WAVES;
+    const float *gp = pos + 3 * (size_t)s;
+    for (int i = tid; i < n; i += FPS_THREADS) dd[i] = 3.0e38f;
+    __syncthreads();
+    float gmin = 3.0e38f;
+    int last = start_idx ? start_idx[b] : 0;
+    if (last < 0 || last >= n) last = 0;
+    if (tid == 0) out_idx[o0] = s + last;
+    for (int k = 1; k < m; ++k) {
+        const float qx = gp[3 * last], qy = gp[3 * last + 1], qz = gp[3 * last + 2];
+        float bv = -1.f;
+        int bi = INT_MAX;
+        for (int i = tid; i < n; i += FPS_THREADS) {
+            const float d = fps_min(dd[i], gn_sqdist3(gp[3 * i], gp[3 * i + 1], gp[3 * i + 2], qx, qy, qz));
+            dd[i] = d;
+            if (d > bv) { bv = d; bi = i; }          // ascending index: ties keep the lowest
+        }
+        const float wv = wave_max_f(bv);
+        const int wi = wave_min_i(bv == wv ? bi : INT_MAX);
+        const int par = (k & 1) * WAVES;
+        if (lane == 0) { pv[par + wave] = wv; pi[par + wave] = wi; }
+        __syncthreads();
+        float fv = pv[par + (lane & (WAVES - 1))];
+        int fi = pi[par + (lane & (WAVES - 1))];
+        const float gv = part_max_f<WAVES>(fv);
+        fi = part_min_i<WAVES>(fv == gv ? fi : INT_MAX);
+        last = __builtin_amdgcn_readfirstlane(fi);
+        gmin = fps_min(gmin, gv);
+        if (tid == 0) out_idx[o0 + k] = s + last;
+    }
+    if (gap_out && tid == 0) gap_out[b] = gmin;
+}
+
 extern "C" int gn_fps_nested(const float *pos, const int32_t *ptr, const int32_t *out_ptr, const int32_t *start_idx, int B,
                              int max_points_per_example, int32_t *out_idx, float *gap_out, const float *nested_gap, void *stream) {
     GN_REQUIRE(B >= 0 && max_points_per_example >= 0, "gn_fps: bad sizes");
     GN_REQUIRE(nested_gap == nullptr || start_idx == nullptr, "gn_fps_nested: a nested sample starts at the example's first point (start_idx must be NULL)");
     if (B == 0 || max_points_per_example == 0) return GN_OK;
     const int n = max_points_per_example;
-    GN_REQUIRE(n <= 16 * FPS_THREADS, "gn_fps: more than %d points per example is not supported (got %d)", 16 * FPS_THREADS, n);
+    GN_REQUIRE(n <= FPS_LDS_MAX, "gn_fps: more than %d points per example is not supported (got %d)", FPS_LDS_MAX, n);
+    if (n > 16 * FPS_THREADS) {                     // beyond the register-resident kernels: running distances in LDS (fps_lds_kernel)
+        const size_t shl = sizeof(float) * (4 * FPS_WAVES + (size_t)n);
+        GN_HIP(hipFuncSetAttribute((const void *)fps_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shl), "gn_fps");
+        hipLaunchKernelGGL(fps_lds_kernel, dim3(B), dim3(FPS_THREADS), shl, gn_stream(stream), pos, ptr, out_ptr, start_idx, out_idx, gap_out, nested_gap);
+        GN_LAUNCH_CHECK("gn_fps");
+        return GN_OK;
+    }
     const bool lds_pos = n <= 8192;
     // ONE wave per SIMD for as long as its points fit the registers (24 per lane): the min-update costs the same issue slots however it is spread, the
     // arg-max reduction and the exchange are paid per wave (n = 6000: 256 threads 2.13 ms, 512 threads 2.26 ms, 1024 threads 3.0 ms)

@@ -49,7 +49,8 @@ def _model(hp, seed):
 
 # ------------------------------------------------------------------------------------------------ point ops
 @pytest.mark.parametrize("sizes,ratio", [([6000, 6000], 0.5), ([3000], 0.25), ([700, 1, 333, 64, 65], 0.5), ([9000], 0.25),
-                                         ([6145, 6144], 0.25), ([8192, 8193], 0.125), ([13000], 0.05)])
+                                         ([6145, 6144], 0.25), ([8192, 8193], 0.125), ([13000], 0.05),
+                                         ([20000, 300], 0.1), ([36864], 0.02)])       # > 16384 points: the LDS-resident kernel (round 6)
 def test_fps_bit_exact(sizes, ratio):
     _, pos, batch = _ragged_cloud(sizes, 3)
     ptr = O.batch_to_ptr(batch.numpy())
