@@ -417,6 +417,7 @@ class HbmMembers:
             return rows * vol_b.shape[-1] * 4 + frac * nb(vol_b)
         self._wrap("trilinear_sample", samp)
         self._wrap("ggm3d_batch", lambda res, vols, *a, **k: 2 * nb(vols))
+        self._wrap("ggm3d_batch_range", lambda res, vols, *a, **k: 2 * nb(vols))      # (round 6: the predict path's form -- the volumes' (min, max) ride along)
         self._wrap("minmax_batch", lambda res, vols, *a, **k: nb(vols))
         self._wrap("mc33_batch", lambda res, vols, *a, **k: nb(vols))          # (+ V * 28 + F * 12 of mesh output: < 1 % of the volume bytes)
         self._wrap("gather_nn_batch", lambda res, vols, verts, *a, **k: nb(verts) + nb(res))
@@ -438,6 +439,8 @@ class HbmMembers:
             g["bytes"] += byts
             g["ms"] += e0.elapsed_time(e1)
             g["calls"] += 1
+        if "ggm3d_batch_range" in groups:            # one name for the GGM launch across rounds
+            groups["ggm3d_batch"] = groups.pop("ggm3d_batch_range")
         out = {}
         for name, g in groups.items():
             gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0
@@ -468,6 +471,20 @@ class HbmMembers:
                 gbs = b_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 sh[k] = {"ms": ms, "algorithmic_bytes": b_, "GBs": gbs, "frac_of_8TBs": gbs / PEAK_HBM_GBS}
             out["iso_on_shell_volume"] = sh
+            # the GGM's two accumulation widths on the step's own volumes (Arith.ggm_fp32; the default is scipy's fp64 arithmetic bit for bit)
+            ab = {}
+            for bits in (64, 32):
+                ops.ggm3d_batch_range(wnf_all, 0.5, bits)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g_ = ops.ggm3d_batch_range(wnf_all, 0.5, bits)[0]
+                e1.record()
+                torch.cuda.synchronize()
+                ab["fp%d" % bits] = (e0.elapsed_time(e1), g_)
+            ref = ab["fp64"][1].double()
+            out["ggm_accumulation"] = {"fp64_ms": ab["fp64"][0], "fp32_ms": ab["fp32"][0],
+                                       "fp32_max_abs_diff_vs_fp64": float((ab["fp32"][1].double() - ref).abs().max()),
+                                       "ggm_max": float(ref.max()), "note": "with the (min, max) record riding along in both"}
         roofs = measured_roofs()
         if roofs is not None:
             out["roofs"] = dict(roofs, public_spec={"fp64_vector_tflops": 78.6, "lds_TBs": "MI355X_MICROARCH.md: ds_read_b128 256 B/clk/CU = 157 TB/s at 2.4 GHz, ~150 measured with every CU streaming"},

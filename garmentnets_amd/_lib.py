@@ -59,6 +59,7 @@ PROTOTYPES = {
     "gn_ggm3d": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
     "gn_minmax": [_vp, _i64, _vp, _vp],
     "gn_ggm3d_batch": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
+    "gn_ggm3d_batch_ex": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _vp],
     "gn_minmax_batch": [_vp, _i32, _i64, _vp, _vp],
     "gn_mc33_batch_workspace_bytes": [_i32, _i32, _i32, _i32],
     "gn_mc33_batch": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],

@@ -28,6 +28,8 @@ global mutable state except immutable LUTs).  ``DEFAULT`` is read from the envir
     fused_lattice      lattice queries sampled INSIDE the decoder-MLP kernel (gn_implicit_decode_lattice_split, no sampled-row buffer in
                        HBM; bit-identical).  OFF by default: measured 16.57 vs 16.48 ms per 16 x 128^3 lattices -- the gather's LDS traffic and the
                        3-stage weight ring cost the decoder kernel what the separate sampler launch costs
+    ggm_fp32           the batched Gaussian gradient magnitude accumulates its taps in fp32 instead of scipy's fp64 (gn_ggm3d_batch_ex, round 6).  OFF by
+                       default: the default is scipy's arithmetic bit for bit; on, `volume_gradient_magnitude` is 1e-6-class against it (meshes unchanged)
 """
 import dataclasses
 import os
@@ -59,6 +61,7 @@ class Arith:
     polyphase_upconv: bool = True
     fold_final_conv: bool = True
     fused_lattice: bool = False
+    ggm_fp32: bool = False
 
     def __post_init__(self):
         if self.conv_mode not in CONV_MODE_NAMES.values():
@@ -81,7 +84,8 @@ class Arith:
                    decode_mode=_env_choice("GARMENTNETS_DECODE_MODE", "f16x2", DECODE_MODES),
                    sparse_first_conv=_env_flag("GARMENTNETS_SPARSE_CONV"), affine_in_weights=_env_flag("GARMENTNETS_AFFINE_IN_WEIGHTS"),
                    winograd=_env_flag("GARMENTNETS_WINOGRAD"), winograd32=_env_flag("GARMENTNETS_WINOGRAD32"), polyphase_upconv=_env_flag("GARMENTNETS_POLYPHASE"),
-                   fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False))
+                   fold_final_conv=_env_flag("GARMENTNETS_FOLD_FINAL_CONV"), fused_lattice=_env_flag("GARMENTNETS_FUSED_LATTICE", False),
+                   ggm_fp32=_env_flag("GARMENTNETS_GGM_FP32", False))
 
     def replace(self, **kw):
         return dataclasses.replace(self, **kw)

@@ -66,7 +66,7 @@ class IsoBatchJob:
     padded buffers, and returns at once; ``finish()`` fetches the B (min, max, #verts, #faces) records in ONE device-to-host copy and
     slices the batch's buffers.  All outputs are this job's own allocations (two jobs in flight never share a buffer)."""
 
-    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent", cap_v=None):
+    def __init__(self, Q, iso_surface_level=0.5, sigma=0.5, gradient_direction="ascent", cap_v=None, ggm_fp32=False):
         """cap_v: vertex capacity per volume (None: 6 Q^2, enough for a garment-like closed surface); a volume that needs more is redone
         on its own in finish() -- a caller that sees such volumes regularly passes what the last batch needed (predict._iso_capacity)"""
         if gradient_direction not in ("ascent", "descent"):
@@ -74,8 +74,10 @@ class IsoBatchJob:
         self.Q, self.level, self.sigma, self.direction = int(Q), float(iso_surface_level), float(sigma), gradient_direction
         self.cap_v = max(4096, int(6 * self.Q ** 2), int(cap_v or 0))
         self.cap_f = 2 * self.cap_v + 64
+        self.ggm_bits = 32 if ggm_fp32 else 64       # Arith.ggm_fp32: taps accumulated in fp32 (opt-in; default = scipy's arithmetic bit for bit)
         self.need_v = 0                              # after finish(): the largest vertex / half face count any volume of the batch asked for
         self.vols, self.ggms, self.mcs, self.recs = [], [], [], []
+        self.ranges = []                             # per enqueue: the (Bp, 2) device (min, max) records (NaN-propagating: any_nan())
         self.padded, self.max_nv = [], 0             # the (Bp, cap_v, 3) float32 query buffers; largest vertex count of the batch
 
     def enqueue(self, wnf_part):
@@ -83,9 +85,10 @@ class IsoBatchJob:
         if Bp == 0:
             return
         vols = wnf_part.float().contiguous()
-        ggm = ops.ggm3d_batch(vols, self.sigma)
+        ggm, rng = ops.ggm3d_batch_range(vols, self.sigma, self.ggm_bits)      # the volumes' (min, max) ride on the GGM's staging pass
         mc = ops.mc33_batch(vols, self.level, self.cap_v, self.cap_f)           # verts, faces, normals, values, counts (device)
-        rec = torch.cat((ops.minmax_batch(vols).double(), mc[4].double()), dim=1)
+        rec = torch.cat((rng.double(), mc[4].double()), dim=1)
+        self.ranges.append(rng)
         # the vertex look-ups on the padded (Bp, cap_v) buffers, before the counts are known (rows past a garment's count are zeros)
         spacing = 1 / (self.Q - 1)
         vf32 = ops.scale_verts(mc[0].view(-1, 3), spacing).view(Bp, self.cap_v, 3)
@@ -97,6 +100,10 @@ class IsoBatchJob:
             self.mcs.append((mc[0][i], mc[1][i], mc[2][i], mc[3][i], mc[4][i], vf32[i], v64[i], vgm[i]))
             self.recs.append(rec[i])
         self.padded.append(vf32)
+
+    def any_nan(self):
+        """device bool: some enqueued volume holds a NaN -- read off the NaN-propagating (min, max) records, no pass over the volumes"""
+        return torch.isnan(torch.cat(self.ranges)).any()
 
     def finish(self):
         """-> list of B entries, each a mesh dict or the exception (ValueError / RuntimeError) scikit-image would have raised"""

@@ -278,6 +278,7 @@ struct DecodeArgs {
 };
 
 #define DEC_TM 32
+#define DEC_MAX_GRID 4096             // workgroups of a launch: 256 CUs x at most 3 resident workgroups, a few rounds of them; each walks its share of the row tiles
 
 // one dense layer on the 32 resident rows: Y[32][N] = bn(relu(X[32][K] W^T + b)), X and Y in LDS (row stride K+4 / N+4
 // floats: 16-byte aligned rows whose 16-byte slots rotate with the row -> conflict-free ds_read_b128).
@@ -399,7 +400,9 @@ __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
     if (p.run_if && *p.run_if == 0.f) return;       // gated launch (the split-operand kernel handled these rows)
     const int ldp = p.C0 + 4, ldq = p.N1 + 4;
     float *P = dsm, *Qb = dsm + DEC_TM * ldp, *red = Qb + DEC_TM * ldq;   // X0 | H1 | 8 x 32 x OUT partial dot products
-    const long long mb = (long long)blockIdx.x * DEC_TM;
+    // a bounded grid walking the row tiles (round 6): a GATED launch that has nothing to do (the common case: the split-operand kernel handled the rows)
+    // costs its workgroups' start-up only -- 21 845 of them for a third of a 128^3 lattice were 8.3 us per launch, 32 launches per 16-garment step
+    for (long long mb = (long long)blockIdx.x * DEC_TM; mb < p.M; mb += (long long)gridDim.x * DEC_TM) {
     // ---- phase 0: X0 = pre-sampled rows (coalesced 16-byte loads) or trilinear sampling of 8 queries per wave
     if (p.xin) {
         const int c4n = p.C0 >> 2;
@@ -464,6 +467,8 @@ __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
             p.out[m * p.ldo + o] = v;
         }
     }
+    __syncthreads();                                 // the next tile's rows overwrite P / red
+    }
 }
 
 extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
@@ -486,10 +491,11 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
     const int ldp = C0 + 4, ldq = N1 + 4;
     const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq + 8 * OUT);
     GN_REQUIRE(sh <= 160 * 1024, "gn_implicit_decode: layer widths need %zu bytes of LDS", sh);
+    const int64_t tiles = gn_cdiv(M, DEC_TM);
 #define DEC_LAUNCH(O)                                                                                                                  \
     do {                                                                                                                               \
         GN_HIP(hipFuncSetAttribute((const void *)implicit_decode_kernel<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_implicit_decode"); \
-        hipLaunchKernelGGL(implicit_decode_kernel<O>, dim3((unsigned)gn_cdiv(M, DEC_TM)), dim3(256), sh, gn_stream(stream), p);        \
+        hipLaunchKernelGGL(implicit_decode_kernel<O>, dim3((unsigned)(tiles < DEC_MAX_GRID ? tiles : DEC_MAX_GRID)), dim3(256), sh, gn_stream(stream), p); \
     } while (0)
     switch (OUT) {
         case 1: DEC_LAUNCH(1); break;

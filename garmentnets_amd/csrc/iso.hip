@@ -21,11 +21,26 @@
 #include <float.h>
 
 // ================================================================================================ GGM
-struct GgmWeights {
-    double w[65];
+template <typename T> struct GgmW {
+    T w[65];
     int radius;
     int symmetric;  // 1 symmetric, -1 antisymmetric, 0 generic
 };
+typedef GgmW<double> GgmWeights;
+// accumulation arithmetic of a correlation: fp64 in scipy's operation order (bit-exact, the default) or the same order in fp32 (gn_ggm3d_batch_ex,
+// accum_bits = 32: no scipy bit-parity, 1e-6-class against it)
+__device__ __forceinline__ double gg_mul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double gg_add(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double gg_sub(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ float gg_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float gg_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float gg_sub(float a, float b) { return __fsub_rn(a, b); }
+// NaN-propagating min / max (IEEE 754-2019 minimum / maximum = numpy.min / numpy.max; one v_minimum3_f32 / v_maximum3_f32 each)
+__device__ __forceinline__ float gn_min_nan(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ float gn_max_nan(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+// order-preserving encodings so that integer atomics implement float min / max; a NaN takes the extreme code of its side and decodes to a NaN
+__device__ __forceinline__ unsigned gn_enc_min(float v) { const unsigned e = __float_as_uint(v); return v != v ? 0u : ((e & 0x80000000u) ? ~e : (e | 0x80000000u)); }
+__device__ __forceinline__ unsigned gn_enc_max(float v) { const unsigned e = __float_as_uint(v); return v != v ? 0xffffffffu : ((e & 0x80000000u) ? ~e : (e | 0x80000000u)); }
 
 // correlate1d along `axis`, edge-replicate, fp64 accumulation in scipy's operation order, fp32 store
 __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1,
@@ -94,34 +109,39 @@ __device__ __forceinline__ float ggm_corr(const float *c, int st, const GgmWeigh
     return (float)acc;
 }
 
-// one correlation output from a register window win[0 .. 2R] (centre at R) -- same operation order as ggm_corr
-__device__ __forceinline__ float ggm_corr_win(const float *win, const GgmWeights &gw) {
+// one correlation output from a register window win[0 .. 2R] (centre at R) -- same operation order as ggm_corr; T = accumulation type
+template <typename T>
+__device__ __forceinline__ float ggm_corr_win(const float *win, const GgmW<T> &gw) {
     constexpr int R = GGM_R;
     const int r = gw.radius;
-    double acc;
+    T acc;
     if (gw.symmetric == 1) {
-        acc = __dmul_rn((double)win[R], gw.w[r]);
+        acc = gg_mul((T)win[R], gw.w[r]);
 #pragma unroll
         for (int j = -R; j < 0; ++j)
-            if (j >= -r) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)win[R + j], (double)win[R - j]), gw.w[r + j]));
+            if (j >= -r) acc = gg_add(acc, gg_mul(gg_add((T)win[R + j], (T)win[R - j]), gw.w[r + j]));
     } else if (gw.symmetric == -1) {
-        acc = __dmul_rn((double)win[R], gw.w[r]);
+        acc = gg_mul((T)win[R], gw.w[r]);
 #pragma unroll
         for (int j = -R; j < 0; ++j)
-            if (j >= -r) acc = __dadd_rn(acc, __dmul_rn(__dsub_rn((double)win[R + j], (double)win[R - j]), gw.w[r + j]));
+            if (j >= -r) acc = gg_add(acc, gg_mul(gg_sub((T)win[R + j], (T)win[R - j]), gw.w[r + j]));
     } else {
-        acc = 0.0;
+        acc = (T)0;
 #pragma unroll
         for (int j = -R; j <= R; ++j)
-            if (j >= -r && j <= r) acc = __dadd_rn(acc, __dmul_rn((double)win[R + j], gw.w[r + j]));
+            if (j >= -r && j <= r) acc = gg_add(acc, gg_mul((T)win[R + j], gw.w[r + j]));
     }
     return (float)acc;
 }
 
 // Every pass walks COLUMNS along its axis with the 2R+1 inputs of an output in a sliding register window: one LDS read per new input
 // instead of 2R+1 per output, and the (z, y, x) decomposition of an index once per column instead of once per output.
+// RANGE: the volume's (min, max) ride along -- every value staged here (tile + edge-replicated halo) IS a voxel of the volume, so the extremes of
+// everything the workgroups load are the volume's; NaN-propagating, one pair of integer atomics per wave on range_enc[2 blockIdx.y ..]
+// (initialised by minmax_init_kernel, decoded by minmax_decode_kernel), issued only by a wave that has an extreme to add.  Saves gn_minmax_batch's pass over the volume.
+template <typename T, bool RANGE>
 __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1, int n2,
-                                                        GgmWeights w0, GgmWeights w1) {
+                                                        GgmW<T> w0, GgmW<T> w1, unsigned *__restrict__ range_enc) {
     // HX: row pitch of the LDS tiles, ONE float of padding: pass 2 walks along x with lane = row, and 37 * row mod 32 is a permutation
     constexpr int R = GGM_R, HZ = GGM_TZ + 2 * R, HY = GGM_TY + 2 * R, HXV = GGM_TX + 2 * R, HX = HXV + 1, WN = 2 * R + 1;
     constexpr int NA = HZ * HY * HX, NB1 = GGM_TZ * HY * HX, NC1 = GGM_TZ * GGM_TY * HX;
@@ -137,6 +157,11 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
     const int y0 = (t % ty_n) * GGM_TY; t /= ty_n;
     const int z0 = t * GGM_TZ;
     const int tid = threadIdx.x;
+    unsigned seen_mn = 0xffffffffu, seen_mx = 0u;    // RANGE: the record so far (device-scope loads, in flight under the tile loads)
+    if constexpr (RANGE) {
+        seen_mn = __hip_atomic_load(range_enc + 2 * blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen_mx = __hip_atomic_load(range_enc + 2 * blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // stage the tile + halo, edge-replicated: rows of HXV consecutive x, a wave per row; ALL of a thread's loads are issued before the first
     // LDS store (36 dependent load -> store round trips per thread were most of this kernel's time)
     {
@@ -157,6 +182,27 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < NROW; ++i)
             if (hx < HXV) A[(w + 4 * i) * HX + hx] = tmp[i];
+        if constexpr (RANGE) {
+            // same-address atomics serialise in the L2 (a pair per wave, unconditionally: 1.41 instead of 0.74 ms for 16 x 128^3), so a wave looks first: the record
+            // as it stood when the workgroup started (a stale look is safe: the record only moves outwards) against each lane's own extremes -- after the first
+            // few workgroups almost no wave has anything to add, and the cross-lane reduction is skipped with the atomics
+            float mn = INFINITY, mx = -INFINITY;
+            if (hx < HXV) {
+#pragma unroll
+                for (int i = 0; i < NROW; ++i) { mn = gn_min_nan(mn, tmp[i]); mx = gn_max_nan(mx, tmp[i]); }
+            }
+            if (__ballot(gn_enc_min(mn) < seen_mn || gn_enc_max(mx) > seen_mx)) {
+                for (int off = 32; off >= 1; off >>= 1) {
+                    mn = gn_min_nan(mn, __shfl_xor(mn, off));
+                    mx = gn_max_nan(mx, __shfl_xor(mx, off));
+                }
+                if (hx == 0) {
+                    unsigned *const slot = range_enc + 2 * blockIdx.y;
+                    if (gn_enc_min(mn) < seen_mn) atomicMin(slot, gn_enc_min(mn));
+                    if (gn_enc_max(mx) > seen_mx) atomicMax(slot + 1, gn_enc_max(mx));
+                }
+            }
+        }
     }
     __syncthreads();
     // pass 0 (axis 0): B[0] = corr(A, w1), B[1] = corr(A, w0) at z = 0 .. TZ-1; a thread owns (hy, hx) columns
@@ -216,7 +262,7 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
             float v = __fmul_rn(t0, t0);
             v = __fadd_rn(v, __fmul_rn(t1, t1));
             v = __fadd_rn(v, __fmul_rn(t2, t2));
-            O[row * OP + xs + x] = (float)__dsqrt_rn((double)v);
+            O[row * OP + xs + x] = sizeof(T) == 8 ? (float)__dsqrt_rn((double)v) : __fsqrt_rn(v);
         }
     }
     __syncthreads();
@@ -247,48 +293,12 @@ static void ggm_kernel1d(double sigma, int order, int radius, GgmWeights &g) {
     g.symmetric = sym ? 1 : (anti ? -1 : 0);
 }
 
-extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
-    GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
-    const int radius = (int)(4.0 * sigma + 0.5);
-    GN_REQUIRE(radius >= 1 && radius <= 32, "gn_ggm3d: unsupported sigma");
-    GN_REQUIRE(tmp != nullptr || radius <= GGM_R, "gn_ggm3d: tmp (2 volumes) is required for a kernel radius above %d", GGM_R);
-    if (batch == 0) return GN_OK;
-    GgmWeights w0, w1;
-    ggm_kernel1d(sigma, 0, radius, w0);
-    ggm_kernel1d(sigma, 1, radius, w1);
-    const int64_t tot = (int64_t)n0 * n1 * n2;
-    float *t1 = tmp, *t2 = tmp + (int64_t)batch * tot;
-    hipStream_t st = gn_stream(stream);
-    if (radius <= GGM_R) {                          // one fused launch (tmp is not touched)
-        const unsigned tiles = (unsigned)(gn_cdiv(n0, GGM_TZ) * gn_cdiv(n1, GGM_TY) * gn_cdiv(n2, GGM_TX));
-        hipLaunchKernelGGL(ggm_fused_kernel, dim3(tiles, (unsigned)batch), dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1);
-        GN_LAUNCH_CHECK("gn_ggm3d");
-        return GN_OK;
-    }
-    dim3 grid((unsigned)gn_cdiv(tot, 256), (unsigned)batch), block(256);
-    // scipy: for axis d, correlate along axes 0, 1, 2 in turn (derivative kernel on d, Gaussian on the others, fp32 between the passes),
-    // square, accumulate in the order d = 0, 1, 2, square root.  The chains of d = 1 and d = 2 both start with the Gaussian along
-    // axis 0 (computed once), and every chain's last pass accumulates directly: 8 passes over the volume instead of 12.
-#define GGM_PASS(SRC, DST, AXIS, W, ACC) hipLaunchKernelGGL(ggm_correlate_kernel, grid, block, 0, st, (const float *)(SRC), DST, n0, n1, n2, AXIS, W, ACC)
-    GGM_PASS(vol, t1, 0, w1, 0); GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w0, 1);     // d = 0
-    GGM_PASS(vol, t1, 0, w0, 0);                                                                // shared by d = 1, 2
-    GGM_PASS(t1, t2, 1, w1, 0); GGM_PASS(t2, out, 2, w0, 2);                                    // d = 1
-    GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w1, 3);                                    // d = 2
-#undef GGM_PASS
-    GN_LAUNCH_CHECK("gn_ggm3d");
-    return GN_OK;
-}
-
-extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
-    return gn_ggm3d_batch(vol, 1, n0, n1, n2, sigma, tmp, out, stream);
-}
-
 // ================================================================================================ min / max
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out_enc) {
     __shared__ float smn[4], smx[4];
     x += (int64_t)blockIdx.y * n;                   // batched: n elements and one (min, max) pair per blockIdx.y
     out_enc += 2 * blockIdx.y;
-    float mn = 3.4e38f, mx = -3.4e38f;
+    float mn = INFINITY, mx = -INFINITY;             // NaN-propagating throughout (numpy.min / numpy.max, what skimage's level check sees)
     // a volume may start anywhere (a slice of an odd-sized batch): scalar head up to the first 16-byte boundary, float4 body, scalar tail
     int64_t head = (int64_t)(((16u - (unsigned)((uintptr_t)x & 15u)) & 15u) >> 2);
     if (head > n) head = n;
@@ -296,33 +306,29 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
     const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 v = x4[i];
-        mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
-        mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        mn = gn_min_nan(gn_min_nan(mn, v.x), gn_min_nan(v.y, gn_min_nan(v.z, v.w)));
+        mx = gn_max_nan(gn_max_nan(mx, v.x), gn_max_nan(v.y, gn_max_nan(v.z, v.w)));
     }
     if (blockIdx.x == 0 && threadIdx.x < 8) {
         const int64_t i = threadIdx.x < 4 ? (int64_t)threadIdx.x : tail0 + (threadIdx.x - 4);
         const bool ok = threadIdx.x < 4 ? (int64_t)threadIdx.x < head : i < n;
         if (ok) {
             const float v = x[i];
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
+            mn = gn_min_nan(mn, v);
+            mx = gn_max_nan(mx, v);
         }
     }
     for (int off = 32; off >= 1; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
+        mn = gn_min_nan(mn, __shfl_xor(mn, off));
+        mx = gn_max_nan(mx, __shfl_xor(mx, off));
     }
     if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-        // order-preserving encodings so that integer atomics implement float min / max (one pair per workgroup)
-        unsigned emn = __float_as_uint(mn), emx = __float_as_uint(mx);
-        emn = (emn & 0x80000000u) ? ~emn : (emn | 0x80000000u);
-        emx = (emx & 0x80000000u) ? ~emx : (emx | 0x80000000u);
-        atomicMin(&out_enc[0], emn);
-        atomicMax(&out_enc[1], emx);
+        mn = gn_min_nan(gn_min_nan(smn[0], smn[1]), gn_min_nan(smn[2], smn[3]));
+        mx = gn_max_nan(gn_max_nan(smx[0], smx[1]), gn_max_nan(smx[2], smx[3]));
+        atomicMin(&out_enc[0], gn_enc_min(mn));     // (one pair per workgroup)
+        atomicMax(&out_enc[1], gn_enc_max(mx));
     }
 }
 __global__ void minmax_init_kernel(unsigned *o) { o += 2 * blockIdx.x; o[0] = 0xffffffffu; o[1] = 0u; }
@@ -350,6 +356,68 @@ extern "C" int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2
 }
 
 extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) { return gn_minmax_batch(x, 1, n, out2, stream); }
+
+// ---- GGM entry points (behind the min / max kernels: the _ex form shares their init / decode launches)
+static int ggm3d_batch_impl(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
+                            void *stream) {
+    GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
+    GN_REQUIRE(accum_bits == 64 || accum_bits == 32, "gn_ggm3d: accum_bits must be 64 (scipy's arithmetic, bit for bit) or 32");
+    const int radius = (int)(4.0 * sigma + 0.5);
+    GN_REQUIRE(radius >= 1 && radius <= 32, "gn_ggm3d: unsupported sigma");
+    GN_REQUIRE(tmp != nullptr || radius <= GGM_R, "gn_ggm3d: tmp (2 volumes) is required for a kernel radius above %d", GGM_R);
+    if (batch == 0) return GN_OK;
+    GgmWeights w0, w1;
+    ggm_kernel1d(sigma, 0, radius, w0);
+    ggm_kernel1d(sigma, 1, radius, w1);
+    const int64_t tot = (int64_t)n0 * n1 * n2;
+    float *t1 = tmp, *t2 = tmp + (int64_t)batch * tot;
+    hipStream_t st = gn_stream(stream);
+    if (radius <= GGM_R) {                          // one fused launch (tmp is not touched)
+        const dim3 grid((unsigned)(gn_cdiv(n0, GGM_TZ) * gn_cdiv(n1, GGM_TY) * gn_cdiv(n2, GGM_TX)), (unsigned)batch);
+        unsigned *enc = reinterpret_cast<unsigned *>(range2);
+        if (range2) hipLaunchKernelGGL(minmax_init_kernel, dim3(batch), dim3(1), 0, st, enc);
+        if (accum_bits == 64) {
+            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<double, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, enc);
+            else hipLaunchKernelGGL((ggm_fused_kernel<double, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, enc);
+        } else {
+            GgmW<float> f0, f1;
+            for (int i = 0; i < 65; ++i) { f0.w[i] = (float)w0.w[i]; f1.w[i] = (float)w1.w[i]; }
+            f0.radius = w0.radius; f0.symmetric = w0.symmetric; f1.radius = w1.radius; f1.symmetric = w1.symmetric;
+            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<float, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, enc);
+            else hipLaunchKernelGGL((ggm_fused_kernel<float, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, enc);
+        }
+        if (range2) hipLaunchKernelGGL(minmax_decode_kernel, dim3(batch), dim3(1), 0, st, enc);
+        GN_LAUNCH_CHECK("gn_ggm3d");
+        return GN_OK;
+    }
+    GN_REQUIRE(accum_bits == 64, "gn_ggm3d: the fp32 accumulation exists for the fused form only (kernel radius <= %d)", GGM_R);
+    dim3 grid((unsigned)gn_cdiv(tot, 256), (unsigned)batch), block(256);
+    // scipy: for axis d, correlate along axes 0, 1, 2 in turn (derivative kernel on d, Gaussian on the others, fp32 between the passes),
+    // square, accumulate in the order d = 0, 1, 2, square root.  The chains of d = 1 and d = 2 both start with the Gaussian along
+    // axis 0 (computed once), and every chain's last pass accumulates directly: 8 passes over the volume instead of 12.
+#define GGM_PASS(SRC, DST, AXIS, W, ACC) hipLaunchKernelGGL(ggm_correlate_kernel, grid, block, 0, st, (const float *)(SRC), DST, n0, n1, n2, AXIS, W, ACC)
+    GGM_PASS(vol, t1, 0, w1, 0); GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w0, 1);     // d = 0
+    GGM_PASS(vol, t1, 0, w0, 0);                                                                // shared by d = 1, 2
+    GGM_PASS(t1, t2, 1, w1, 0); GGM_PASS(t2, out, 2, w0, 2);                                    // d = 1
+    GGM_PASS(t1, t2, 1, w0, 0); GGM_PASS(t2, out, 2, w1, 3);                                    // d = 2
+#undef GGM_PASS
+    GN_LAUNCH_CHECK("gn_ggm3d");
+    if (range2) return gn_minmax_batch(vol, batch, tot, range2, stream);      // the 8-pass form has no staging pass to ride on
+    return GN_OK;
+}
+
+extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
+    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, 64, nullptr, stream);
+}
+
+extern "C" int gn_ggm3d_batch_ex(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
+                                 void *stream) {
+    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, accum_bits, range2, stream);
+}
+
+extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
+    return gn_ggm3d_batch(vol, 1, n0, n1, n2, sigma, tmp, out, stream);
+}
 
 // ================================================================================================ MC33
 __device__ const int8_t MC_LUT_G[MC_LUT_BYTES] = MC_LUT_INITIALIZER;

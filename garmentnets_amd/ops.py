@@ -776,8 +776,20 @@ def ggm3d_batch(vols, sigma):
     return out
 
 
+def ggm3d_batch_range(vols, sigma, accum_bits=64):
+    """ggm3d_batch + the (B,2) float32 (min, max) record of every volume from the same launch (NaN-propagating like numpy's; no pass of its own
+    over the volumes: gn_ggm3d_batch_ex).  accum_bits=32: the taps accumulate in fp32 (no scipy bit-parity; Arith.ggm_fp32)"""
+    _chk(vols, torch.float32, "vols")
+    B, n0, n1, n2 = vols.shape
+    tmp = _ggm_tmp(vols.shape, sigma, vols.device)
+    out = torch.empty_like(vols)
+    rng = torch.empty((B, 2), dtype=torch.float32, device=vols.device)
+    _lib.call("gn_ggm3d_batch_ex", _p(vols), B, n0, n1, n2, float(sigma), _p(tmp), _p(out), int(accum_bits), _p(rng), _stream())
+    return out, rng
+
+
 def minmax_batch(vols):
-    """-> (B,2) float32: (min, max) of every volume of a (B,...) batch"""
+    """-> (B,2) float32: (min, max) of every volume of a (B,...) batch (NaN-propagating: a NaN anywhere gives NaN, as numpy.min / numpy.max)"""
     _chk(vols, torch.float32, "vols")
     B = vols.shape[0]
     out = torch.empty((B, 2), dtype=torch.float32, device=vols.device)

@@ -169,9 +169,11 @@ def _dense_phase(model, batch, volume_size, iso_surface_level, gradient_sigma, g
         # iso-surfaces of the whole batch with one host synchronisation (fixed level; auto_level needs each volume's range first)
         job = None
         if not auto_level:
-            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, cap_v=_iso_capacity(model, volume_size))
+            job = mcu.IsoBatchJob(volume_size, iso_surface_level, gradient_sigma, gradient_direction, cap_v=_iso_capacity(model, volume_size),
+                                  ggm_fp32=arith.ggm_fp32)
             job.enqueue(wnf_all)
-        bad = torch.isnan(wnf_all).any()             # read after the batch's own host synchronisation
+        # (read after the batch's own host synchronisation; with a job: off its NaN-propagating range records -- no second pass over the volumes)
+        bad = job.any_nan() if job is not None and B > 0 else torch.isnan(wnf_all).any()
         # grip-point post-processing, predict.py:254-274, for the whole batch at once (a handful of launches instead of ~10 per garment)
         bins = model.pointnet2_nocs.nocs_bins
         glog_all = pointnet2_result["global_logits"].reshape(B, bins, 3)

@@ -334,12 +334,21 @@ int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const floa
  * tmp (may be NULL); larger radii run 8 separable passes through tmp: 2 volumes of workspace. */
 int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream);
 
-/* min / max of a float array (device result [2]); level-range check of skimage marching_cubes. */
+/* min / max of a float array (device result [2]); level-range check of skimage marching_cubes (measure/_marching_cubes_lewiner.py: volume.min() /
+ * volume.max(): numpy's NaN-propagating reductions -- a NaN anywhere gives NaN in the record, round 6; before: fminf / fmaxf). */
 int gn_minmax(const float *x, int64_t n, float *out2, void *stream);
 /* the same for `batch` volumes of one shape in one set of launches (one volume per blockIdx.y): vol / out [batch][n0][n1][n2],
  * tmp [2][batch][n0][n1][n2]; x [batch][n] (n % 4 == 0), out2 [batch][2].  What predict.py:160-181 does garment by garment. */
 int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream);
 int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2, void *stream);
+/* gn_ggm3d_batch with two options (round 6; predict.py:160-171 needs the volume's range next to its gradient magnitude):
+ *   range2 != NULL  [batch][2]: (min, max) of every volume, NaN-propagating, computed from the values the fused launch stages anyway (its tiles and
+ *                   edge-replicated halos are voxels of the volume) -- no pass of its own over the volume, equal to gn_minmax_batch bit for bit;
+ *                   a kernel radius above 2 (8-pass form) calls gn_minmax_batch.
+ *   accum_bits      64: scipy's arithmetic (fp64 taps), bit for bit, = gn_ggm3d_batch.  32: the same operation order accumulated in fp32 (fused form
+ *                   only): 1e-6-class against scipy, not bit-compatible -- an opt-in for callers that hold floats to a tolerance. */
+int gn_ggm3d_batch_ex(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
+                      void *stream);
 
 /* Lewiner marching cubes (MC33).  replaces skimage.measure.marching_cubes(method='lewiner') -- predict.py:172-177.
  * gn_mc33_workspace_bytes: bytes of `ws` for a volume of n0*n1*n2.

@@ -50,7 +50,9 @@ def _model(hp, seed):
 # ------------------------------------------------------------------------------------------------ point ops
 @pytest.mark.parametrize("sizes,ratio", [([6000, 6000], 0.5), ([3000], 0.25), ([700, 1, 333, 64, 65], 0.5), ([9000], 0.25),
                                          ([6145, 6144], 0.25), ([8192, 8193], 0.125), ([13000], 0.05),
-                                         ([20000, 300], 0.1), ([36864], 0.02)])       # > 16384 points: the LDS-resident kernel (round 6)
+                                         ([20000, 300], 0.1), ([36864], 0.02),        # > 16384 points: the LDS-resident kernel (round 6)
+                                         # 1025 .. 8192 points: the spatially pruned kernel (round 6) -- ragged batches, every block count
+                                         ([6000, 5, 1, 1500, 64], 0.5), ([8192, 1025], 0.25), ([2048, 4100], 0.5), ([5000, 7168, 3073], 0.1)])
 def test_fps_bit_exact(sizes, ratio):
     _, pos, batch = _ragged_cloud(sizes, 3)
     ptr = O.batch_to_ptr(batch.numpy())
@@ -75,6 +77,38 @@ def test_fps_ties_keep_the_lowest_index(sizes):
     cseg = Segments([ops.fps_count(n, 0.5) for n in sizes], DEV)
     idx = ops.fps(pos.to(DEV), seg.ptr, cseg.ptr, max(sizes), cseg.total)
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref)
+
+
+@pytest.mark.parametrize("n", [6000, 2500, 8000])
+def test_fps_pruned_kernel_on_structured_clouds(n):
+    """the spatially pruned kernel (fps_region_kernel: blocks whose bounding box the new sample cannot reach are skipped) on clouds where the skip
+    rule has the most to decide: a thin shell (a surface, like a garment), tight clusters far apart (most blocks skipped from the first steps on),
+    one cluster of exact duplicates (zero-extent boxes, running maxima that reach 0), points on a line (degenerate bounding box), and a flat sheet
+    with lattice ties -- every index list is the oracle's"""
+    g = torch.Generator().manual_seed(n)
+    u = torch.randn(n, 3, generator=g)
+    shell = u / u.norm(dim=1, keepdim=True) * (0.4 + 0.002 * torch.rand(n, 1, generator=g))
+    centres = torch.rand(12, 3, generator=g) * 10
+    clusters = centres[torch.randint(0, 12, (n,), generator=g)] + 1e-3 * torch.randn(n, 3, generator=g)
+    dup = clusters.clone()
+    dup[: 2 * n // 3] = dup[0]
+    line = torch.zeros(n, 3)
+    line[:, 1] = torch.rand(n, generator=g)
+    sheet = torch.cat([torch.randint(0, 40, (n, 2), generator=g).float() / 40, torch.zeros(n, 1)], dim=1)
+    clouds = [shell, clusters, dup, line, sheet]
+    sizes = [n] * len(clouds)
+    pos = torch.cat(clouds).float().contiguous()
+    ptr = np.arange(0, (len(clouds) + 1) * n, n, dtype=np.int64)
+    ref, optr = O.fps(pos.numpy(), ptr, 0.5)
+    seg = Segments(sizes, DEV)
+    cseg = Segments([ops.fps_count(n, 0.5)] * len(clouds), DEV)
+    gap = torch.empty(len(clouds), dtype=torch.float32, device=DEV)
+    idx = ops.fps(pos.to(DEV), seg.ptr, cseg.ptr, n, cseg.total, gap_out=gap)
+    got = idx.cpu().numpy().astype(np.int64)
+    for b in range(len(clouds)):
+        assert np.array_equal(got[optr[b]:optr[b + 1]], ref[optr[b]:optr[b + 1]]), ("cloud", b)
+    gp = gap.cpu().numpy()
+    assert gp[0] > 0 and gp[1] > 0 and gp[2] == 0 and gp[3] > 0         # the smallest running maximum: what gn_fps_nested's shortcut rests on
 
 
 def test_fps_nested_sample_is_the_plain_sample():
@@ -379,6 +413,63 @@ def test_batched_iso_operators_equal_single_volume_calls(Q, B):
         assert torch.equal(verts[b, :nv], v1[:nv]) and torch.equal(faces[b, :nf], f1[:nf])
         assert torch.equal(normals[b, :nv], n1[:nv]) and torch.equal(values[b, :nv], a1[:nv])
     assert ops.mc33_batch(vols[:0], 0.5, 8, 8)[4].shape == (0, 2)
+
+
+@pytest.mark.parametrize("Q,B", [(32, 5), (20, 3), (128, 3)])
+def test_ggm_range_rides_along(Q, B):
+    """gn_ggm3d_batch_ex (round 6): the gradient magnitude is gn_ggm3d_batch's bit for bit, the (min, max) record that rides on the fused launch's
+    staging pass is gn_minmax_batch's and numpy's; a NaN anywhere in a volume gives NaN in ITS record only (numpy.min / numpy.max: what skimage's
+    level check evaluates, and what predict reads its NaN flag from); infinities are ordinary extremes"""
+    g = torch.Generator().manual_seed(7 * Q + B)
+    base = torch.from_numpy(S.shell_volume(Q)).float()
+    vols = torch.stack([base * (0.6 + 0.2 * b) - 0.3 * b + 0.02 * b * torch.rand(Q, Q, Q, generator=g) for b in range(B)])
+    vols[1] = -0.0
+    vols = vols.to(DEV)
+    ggm, rng = ops.ggm3d_batch_range(vols, 0.5)
+    assert torch.equal(ggm, ops.ggm3d_batch(vols, 0.5))
+    assert torch.equal(rng, ops.minmax_batch(vols))
+    host = vols.cpu().numpy()
+    assert np.array_equal(rng.cpu().numpy(), np.stack([host.reshape(B, -1).min(1), host.reshape(B, -1).max(1)], 1))
+    assert rng[1].tolist() == [0.0, 0.0]
+    # a NaN in the last voxel of volume 0 (a corner: seen through the halo replication of one tile only), infinities in volume 2
+    bad = vols.clone()
+    bad[0, -1, -1, -1] = float("nan")
+    bad[2, 3, 4, 5] = float("inf")
+    bad[2, 5, 4, 3] = float("-inf")
+    _, r2 = ops.ggm3d_batch_range(bad, 0.5)
+    r2 = r2.cpu().numpy()
+    assert np.isnan(r2[0]).all() and not np.isnan(r2[1:]).any()
+    assert r2[2].tolist() == [float("-inf"), float("inf")] and np.array_equal(r2[1], rng[1].cpu().numpy())
+    mm = ops.minmax_batch(bad).cpu().numpy()
+    assert np.isnan(mm[0]).all() and mm[2].tolist() == [float("-inf"), float("inf")]
+    job = MCU.IsoBatchJob(Q)
+    job.enqueue(bad)
+    assert bool(job.any_nan())
+    job = MCU.IsoBatchJob(Q)
+    job.enqueue(vols)
+    assert not bool(job.any_nan())
+
+
+@pytest.mark.parametrize("Q", [32, 128])
+def test_ggm_fp32_accumulation_is_held_to_a_tolerance(Q):
+    """Arith.ggm_fp32 / gn_ggm3d_batch_ex(accum_bits=32): the taps accumulate in fp32 in scipy's operation order -- no bit parity with scipy, held to
+    2e-6 of the volume's largest gradient magnitude (measured 3e-7 .. 5e-7: three passes of 5 taps at 6e-8 each); the range record is the same"""
+    g = torch.Generator().manual_seed(Q)
+    base = torch.from_numpy(S.shell_volume(Q)).float()
+    vols = torch.stack([base, base * 3.0 + 0.1 * torch.rand(Q, Q, Q, generator=g), torch.randn(Q, Q, Q, generator=g)]).to(DEV)
+    g64, r64 = ops.ggm3d_batch_range(vols, 0.5, 64)
+    g32, r32 = ops.ggm3d_batch_range(vols, 0.5, 32)
+    assert torch.equal(r64, r32)
+    for b in range(vols.shape[0]):
+        top = float(g64[b].max())
+        err = float((g32[b].double() - g64[b].double()).abs().max())
+        assert 0 < err <= 2e-6 * top, (b, err, top)
+    with pytest.raises(ValueError):
+        ops.ggm3d_batch_range(vols, 0.5, 16)
+    with pytest.raises(ValueError):                  # the 8-pass form (kernel radius above 2) has no fp32 variant
+        ops.ggm3d_batch_range(vols, 1.0, 32)
+    g1, r1 = ops.ggm3d_batch_range(vols, 1.0, 64)    # ... and takes its range from gn_minmax_batch
+    assert torch.equal(g1, ops.ggm3d_batch(vols, 1.0)) and torch.equal(r1, r64)
 
 
 def test_degenerate_sizes():
