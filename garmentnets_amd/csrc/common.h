@@ -53,6 +53,13 @@ hipStream_t gn_stream(void *s);
 // name of the kernel variant the last gn_conv3d_* call of this thread launched (bench.py labels its roofline with it)
 void gn_note_kernel(const char *name);
 static inline int64_t gn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// zero a pair of fp64 statistics buffers (sum, sumsq: n values each) that a kernel accumulates into with atomics: ONE fill when the caller laid them out back
+// to back (ops._stats_buffers does) -- a fill is ~5 us of stream time, and a 32^3 UNet layer is not much longer than that
+static inline hipError_t gn_zero_stats(double *sum, double *sumsq, size_t n, hipStream_t st) {
+    if (sumsq == sum + n) return hipMemsetAsync(sum, 0, 2 * n * sizeof(double), st);
+    hipError_t e = hipMemsetAsync(sum, 0, n * sizeof(double), st);
+    return e != hipSuccess ? e : hipMemsetAsync(sumsq, 0, n * sizeof(double), st);
+}
 
 // squared distance in the pinned operation order ((dx*dx + dy*dy) + dz*dz), fp32, no FMA contraction
 // (the library is compiled with -ffp-contract=off; the intrinsics make it explicit).

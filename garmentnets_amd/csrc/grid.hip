@@ -217,8 +217,7 @@ extern "C" int gn_grid_stats(const float *vol, const int32_t *flat_idx, int64_t 
                              int32_t *count_ws, double *sum, double *sumsq, void *stream) {
     GN_REQUIRE(N >= 0 && C > 0 && cells_per_sample > 0 && B >= 0, "gn_grid_stats: bad sizes");
     hipStream_t st = gn_stream(stream);
-    GN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * (size_t)B * C, st), "gn_grid_stats");
-    GN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * (size_t)B * C, st), "gn_grid_stats");
+    GN_HIP(gn_zero_stats(sum, sumsq, (size_t)B * C, st), "gn_grid_stats");
     if (N == 0) return GN_OK;
     hipLaunchKernelGGL(grid_stats_kernel, dim3((unsigned)gn_cdiv(N, GS_PTS)), dim3(256), 0, st, vol, flat_idx, N, C, cells_per_sample,
                        count_ws, sum, sumsq);

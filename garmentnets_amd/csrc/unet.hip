@@ -52,8 +52,7 @@ extern "C" int gn_channel_stats(const float *x, int B, int64_t V, int C, double 
     GN_REQUIRE(B >= 0 && V >= 0 && C > 0, "gn_channel_stats: bad sizes");
     GN_REQUIRE((C <= 256 && 256 % C == 0) || (C % 256 == 0), "gn_channel_stats: C=%d must divide 256 or be a multiple of it", C);
     hipStream_t st = gn_stream(stream);
-    GN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * (size_t)B * C, st), "gn_channel_stats");
-    GN_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * (size_t)B * C, st), "gn_channel_stats");
+    GN_HIP(gn_zero_stats(sum, sumsq, (size_t)B * C, st), "gn_channel_stats");
     if (B == 0 || V == 0) return GN_OK;
     hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)gn_cdiv(V, STATS_VOX_PER_BLOCK), B), dim3(256), 0, st, x, V, C, sum, sumsq);
     GN_LAUNCH_CHECK("gn_channel_stats");
@@ -362,8 +361,7 @@ extern "C" int gn_conv3d_gcr(const float *src0, int C0, const float *src1, int C
     if (B == 0) return GN_OK;
     hipStream_t st = gn_stream(stream);
     if (out_sum) {
-        GN_HIP(hipMemsetAsync(out_sum, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr");
-        GN_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr");
+        GN_HIP(gn_zero_stats(out_sum, out_sumsq, (size_t)B * Cout, st), "gn_conv3d_gcr");
     }
     ConvArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = wp; p.out = out; p.osum = out_sum; p.osq = out_sumsq;
@@ -446,8 +444,7 @@ extern "C" int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C
     if (B == 0 || Vp == 0) return GN_OK;
     hipStream_t st = gn_stream(stream);
     if (out_sum) {
-        GN_HIP(hipMemsetAsync(out_sum, 0, sizeof(double) * (size_t)B * C, st), "gn_maxpool3d_2");
-        GN_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double) * (size_t)B * C, st), "gn_maxpool3d_2");
+        GN_HIP(gn_zero_stats(out_sum, out_sumsq, (size_t)B * C, st), "gn_maxpool3d_2");
     }
     hipLaunchKernelGGL(maxpool3d_2_kernel, dim3((unsigned)gn_cdiv(Vp, MP_VPB), B), dim3(256), 0, st, in, D, H, W, C, out, out_sum, out_sumsq);
     GN_LAUNCH_CHECK("gn_maxpool3d_2");

@@ -1002,8 +1002,7 @@ static int conv3d_gcr_split_impl(const float *src0, int C0, const float *src1, i
     if (B == 0) return GN_OK;
     hipStream_t st = gn_stream(stream);
     if (out_sum) {
-        GN_HIP(hipMemsetAsync(out_sum, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr_split");
-        GN_HIP(hipMemsetAsync(out_sumsq, 0, sizeof(double) * (size_t)B * Cout, st), "gn_conv3d_gcr_split");
+        GN_HIP(gn_zero_stats(out_sum, out_sumsq, (size_t)B * Cout, st), "gn_conv3d_gcr_split");
     }
     SplitArgs p;
     p.src0 = src0; p.src1 = src1; p.a = a; p.d = d; p.wp = (const uint4 *)wp_planes; p.out = out; p.osum = out_sum; p.osq = out_sumsq;

@@ -276,8 +276,7 @@ def channel_stats(x):
     """x channel-last [B][D][H][W][C] -> (sum, sumsq) fp64 [B][C]"""
     B, C = x.shape[0], x.shape[-1]
     V = x.numel() // (B * C)
-    s = torch.empty((B, C), dtype=torch.float64, device=x.device)
-    q = torch.empty((B, C), dtype=torch.float64, device=x.device)
+    s, q = _stats_buffers(B, C, x.device, True)
     _lib.call("gn_channel_stats", _p(x), B, V, C, _p(s), _p(q), _stream())
     return s, q, V
 
@@ -553,7 +552,8 @@ def _occupancy_ws(tile_active, B, D, H, W, device):
 def _stats_buffers(B, C, device, want):
     if not want:
         return None, None
-    return (torch.empty((B, C), dtype=torch.float64, device=device), torch.empty((B, C), dtype=torch.float64, device=device))
+    sq = torch.empty((2, B, C), dtype=torch.float64, device=device)      # back to back: the library zeroes the pair with one fill (gn_zero_stats)
+    return sq[0], sq[1]
 
 
 def conv3d_gcr(src0, src1, a, d, wp, cout, relu=True, with_stats=False):
