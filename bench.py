@@ -272,7 +272,7 @@ class KernelTimer:
 
 
 GGM_FP64_INSTR_PER_VOXEL = 120.0     # 9 five-tap symmetric correlations (7 fp64 instructions + 5 fp32->fp64 conversions each) + squares, sums, sqrt
-GGM_LDS_BYTES_PER_VOXEL = 59 * 4.0   # sliding-window reads + inter-pass writes of the fused kernel (csrc/iso.hip ggm_fused_kernel)
+GGM_LDS_BYTES_PER_VOXEL = 25.25 * 4.0   # csrc/iso.hip ggm_fused_kernel at its 4 x 8 x 32 tile: staging 3456 + pass 0 444 columns x 16 + pass 1 148 x 48 + pass 2 256 x 28 + 1024 words per 1024 voxels
 
 
 def fp32_twin_accounting(step):
@@ -474,13 +474,16 @@ class HbmMembers:
             # the GGM's two accumulation widths on the step's own volumes (Arith.ggm_fp32; the default is scipy's fp64 arithmetic bit for bit)
             ab = {}
             for bits in (64, 32):
-                ops.ggm3d_batch_range(wnf_all, 0.5, bits)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                g_ = ops.ggm3d_batch_range(wnf_all, 0.5, bits)[0]
-                e1.record()
-                torch.cuda.synchronize()
-                ab["fp%d" % bits] = (e0.elapsed_time(e1), g_)
+                best, g_ = None, None
+                for _ in range(4):                                   # (the first calls of a variant pay its allocations: fastest of the later ones)
+                    g_ = None
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    g_ = ops.ggm3d_batch_range(wnf_all, 0.5, bits)[0]
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
+                ab["fp%d" % bits] = (best, g_)
             ref = ab["fp64"][1].double()
             out["ggm_accumulation"] = {"fp64_ms": ab["fp64"][0], "fp32_ms": ab["fp32"][0],
                                        "fp32_max_abs_diff_vs_fp64": float((ab["fp32"][1].double() - ref).abs().max()),
@@ -510,8 +513,8 @@ class HbmMembers:
         out["note"] = ("one untimed step; bytes = algorithmic (each input / output of the call once); scatter is atomics / latency-bound by nature "
                        "(6000 points per garment), zero-fill runs on a side stream beside farthest-point sampling; GGM is ONE fused launch at the algorithmic minimum of HBM bytes (one read, one write); its three "
                        "fractions (frac_of_8TBs, frac_of_fp64_rate, frac_of_lds_rate against the ceilings measured in `roofs`) are ALL small: it is bound by "
-                       "none of the three but by latency / occupancy -- 9 dependent five-tap fp64 chains per voxel (scipy's arithmetic, bit for bit) at the "
-                       "few waves per SIMD its 33 KB tiles allow; the MC33 "
+                       "none of the three but by latency -- 9 dependent five-tap fp64 chains per voxel (scipy's arithmetic, bit for bit), four barrier-separated phases; "
+                       "round 6: 4 x 8 x 32 tiles (28 KB of LDS: 5 waves per SIMD instead of 2) took it from 0.72 to 0.42 ms, and the volumes' (min, max) ride on its staging pass; the MC33 "
                        "stages do per-cell fp64 case analysis and per-vertex fp64 gathers: their time follows the number of surface cells, not the bytes")
         return out
 

@@ -59,7 +59,8 @@ PROTOTYPES = {
     "gn_ggm3d": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
     "gn_minmax": [_vp, _i64, _vp, _vp],
     "gn_ggm3d_batch": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
-    "gn_ggm3d_batch_ex": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _vp],
+    "gn_ggm3d_range_workspace_bytes": [_i32, _i32, _i32, _i32],
+    "gn_ggm3d_batch_ex": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _i32, _vp, _vp, _sz, _vp],
     "gn_minmax_batch": [_vp, _i32, _i64, _vp, _vp],
     "gn_mc33_batch_workspace_bytes": [_i32, _i32, _i32, _i32],
     "gn_mc33_batch": [_vp, _i32, _i32, _i32, _i32, _f64, _vp, _sz, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
@@ -78,7 +79,7 @@ PROTOTYPES = {
     "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],
 }
-_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_conv_affine_pack_wino_bytes": _sz, "gn_conv3d_occupancy_workspace_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz, "gn_mesh_largest_component_workspace_bytes": _sz}
+_RESTYPES = {"gn_conv_affine_pack_bytes": _sz, "gn_conv_affine_pack_wino_bytes": _sz, "gn_conv3d_occupancy_workspace_bytes": _sz, "gn_mc33_workspace_bytes": _sz, "gn_ggm3d_range_workspace_bytes": _sz, "gn_mc33_batch_workspace_bytes": _sz, "gn_grid_scatter_workspace_bytes": _sz, "gn_mesh_compact_workspace_bytes": _sz, "gn_mesh_largest_component_workspace_bytes": _sz}
 
 _lib = None
 

@@ -90,8 +90,12 @@ __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restr
 // of the 8-pass form (fp64 accumulation in scipy's order, fp32 rounding between the passes, correctly rounded sqrt), bit for bit, with
 // the compulsory HBM traffic only: each voxel read once (+ halo, mostly L2 hits) and written once instead of 8 round trips.
 #define GGM_R 2
-#define GGM_TZ 8
+#ifndef GGM_TZ
+#define GGM_TZ 4                     // (round 6: 8 -> 4: 28 instead of 57 KB of LDS per workgroup = 5 instead of 2 waves per SIMD; 0.72 -> 0.42 ms per 16 x 128^3)
+#endif
+#ifndef GGM_TY
 #define GGM_TY 8
+#endif
 #define GGM_TX 32
 __device__ __forceinline__ float ggm_corr(const float *c, int st, const GgmWeights &gw) {
     const int r = gw.radius;
@@ -137,11 +141,11 @@ __device__ __forceinline__ float ggm_corr_win(const float *win, const GgmW<T> &g
 // Every pass walks COLUMNS along its axis with the 2R+1 inputs of an output in a sliding register window: one LDS read per new input
 // instead of 2R+1 per output, and the (z, y, x) decomposition of an index once per column instead of once per output.
 // RANGE: the volume's (min, max) ride along -- every value staged here (tile + edge-replicated halo) IS a voxel of the volume, so the extremes of
-// everything the workgroups load are the volume's; NaN-propagating, one pair of integer atomics per wave on range_enc[2 blockIdx.y ..]
-// (initialised by minmax_init_kernel, decoded by minmax_decode_kernel), issued only by a wave that has an extreme to add.  Saves gn_minmax_batch's pass over the volume.
+// everything the workgroups load are the volume's; NaN-propagating; a pair per wave in range_ws, folded per volume by ggm_range_reduce_kernel.  Saves
+// gn_minmax_batch's pass over the volume.
 template <typename T, bool RANGE>
 __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict__ in, float *__restrict__ out, int n0, int n1, int n2,
-                                                        GgmW<T> w0, GgmW<T> w1, unsigned *__restrict__ range_enc) {
+                                                        GgmW<T> w0, GgmW<T> w1, float *__restrict__ range_ws) {
     // HX: row pitch of the LDS tiles, ONE float of padding: pass 2 walks along x with lane = row, and 37 * row mod 32 is a permutation
     constexpr int R = GGM_R, HZ = GGM_TZ + 2 * R, HY = GGM_TY + 2 * R, HXV = GGM_TX + 2 * R, HX = HXV + 1, WN = 2 * R + 1;
     constexpr int NA = HZ * HY * HX, NB1 = GGM_TZ * HY * HX, NC1 = GGM_TZ * GGM_TY * HX;
@@ -157,11 +161,6 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
     const int y0 = (t % ty_n) * GGM_TY; t /= ty_n;
     const int z0 = t * GGM_TZ;
     const int tid = threadIdx.x;
-    unsigned seen_mn = 0xffffffffu, seen_mx = 0u;    // RANGE: the record so far (device-scope loads, in flight under the tile loads)
-    if constexpr (RANGE) {
-        seen_mn = __hip_atomic_load(range_enc + 2 * blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen_mx = __hip_atomic_load(range_enc + 2 * blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     // stage the tile + halo, edge-replicated: rows of HXV consecutive x, a wave per row; ALL of a thread's loads are issued before the first
     // LDS store (36 dependent load -> store round trips per thread were most of this kernel's time)
     {
@@ -183,24 +182,21 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
         for (int i = 0; i < NROW; ++i)
             if (hx < HXV) A[(w + 4 * i) * HX + hx] = tmp[i];
         if constexpr (RANGE) {
-            // same-address atomics serialise in the L2 (a pair per wave, unconditionally: 1.41 instead of 0.74 ms for 16 x 128^3), so a wave looks first: the record
-            // as it stood when the workgroup started (a stale look is safe: the record only moves outwards) against each lane's own extremes -- after the first
-            // few workgroups almost no wave has anything to add, and the cross-lane reduction is skipped with the atomics
+            // one plain (min, max) store per wave into range_ws [volume][tile][wave]; ggm_range_reduce_kernel folds a volume's pairs afterwards.  (Atomics on the
+            // volume's one record serialise in the L2 however they are thinned: every workgroup of the first generation -- at B = 1 that is all of them -- sees the
+            // empty record; measured 0.95 against 0.42 ms for 16 x 128^3, A/B record section 11)
             float mn = INFINITY, mx = -INFINITY;
             if (hx < HXV) {
 #pragma unroll
                 for (int i = 0; i < NROW; ++i) { mn = gn_min_nan(mn, tmp[i]); mx = gn_max_nan(mx, tmp[i]); }
             }
-            if (__ballot(gn_enc_min(mn) < seen_mn || gn_enc_max(mx) > seen_mx)) {
-                for (int off = 32; off >= 1; off >>= 1) {
-                    mn = gn_min_nan(mn, __shfl_xor(mn, off));
-                    mx = gn_max_nan(mx, __shfl_xor(mx, off));
-                }
-                if (hx == 0) {
-                    unsigned *const slot = range_enc + 2 * blockIdx.y;
-                    if (gn_enc_min(mn) < seen_mn) atomicMin(slot, gn_enc_min(mn));
-                    if (gn_enc_max(mx) > seen_mx) atomicMax(slot + 1, gn_enc_max(mx));
-                }
+            for (int off = 32; off >= 1; off >>= 1) {
+                mn = gn_min_nan(mn, __shfl_xor(mn, off));
+                mx = gn_max_nan(mx, __shfl_xor(mx, off));
+            }
+            if (hx == 0) {
+                float2 *slot = reinterpret_cast<float2 *>(range_ws) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + w;
+                *slot = make_float2(mn, mx);
             }
         }
     }
@@ -247,8 +243,9 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
     float *const O = B;
     constexpr int OP = GGM_TX + 1;
     {
-        constexpr int XC = GGM_TX / 4;
-        const int row = tid & 63, xs = (tid >> 6) * XC;
+        constexpr int ROWS = GGM_TZ * GGM_TY, XC = GGM_TX / (256 / ROWS);     // a thread owns XC consecutive x of one (z, y) row
+        static_assert(256 % ROWS == 0 && GGM_TX % (256 / ROWS) == 0 && (ROWS & (ROWS - 1)) == 0, "pass 2: 256 threads = rows x x-chunks");
+        const int row = tid & (ROWS - 1), xs = (tid / ROWS) * XC;
         const float *c0 = C + row * HX + xs, *c1 = c0 + NC1, *c2 = c0 + 2 * NC1;
         float w0v[WN], w1v[WN], w2v[WN];
 #pragma unroll
@@ -357,9 +354,28 @@ extern "C" int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2
 
 extern "C" int gn_minmax(const float *x, int64_t n, float *out2, void *stream) { return gn_minmax_batch(x, 1, n, out2, stream); }
 
-// ---- GGM entry points (behind the min / max kernels: the _ex form shares their init / decode launches)
+// ---- GGM entry points
+// one workgroup per volume folds the npairs (min, max) pairs the fused launch's waves left in range_ws -> out2 [volume] = (min, max), NaN-propagating
+__global__ __launch_bounds__(256) void ggm_range_reduce_kernel(const float2 *__restrict__ ws, int npairs, float *__restrict__ out2) {
+    __shared__ float smn[4], smx[4];
+    ws += (size_t)blockIdx.x * npairs;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < npairs; i += 256) { const float2 v = ws[i]; mn = gn_min_nan(mn, v.x); mx = gn_max_nan(mx, v.y); }
+    for (int off = 32; off >= 1; off >>= 1) { mn = gn_min_nan(mn, __shfl_xor(mn, off)); mx = gn_max_nan(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[2 * blockIdx.x] = gn_min_nan(gn_min_nan(smn[0], smn[1]), gn_min_nan(smn[2], smn[3]));
+        out2[2 * blockIdx.x + 1] = gn_max_nan(gn_max_nan(smx[0], smx[1]), gn_max_nan(smx[2], smx[3]));
+    }
+}
+
+static int64_t ggm_tiles(int n0, int n1, int n2) { return gn_cdiv(n0, GGM_TZ) * gn_cdiv(n1, GGM_TY) * gn_cdiv(n2, GGM_TX); }
+extern "C" size_t gn_ggm3d_range_workspace_bytes(int batch, int n0, int n1, int n2) {
+    return (size_t)(batch > 0 ? batch : 0) * (size_t)ggm_tiles(n0, n1, n2) * 4 * sizeof(float2);
+}
 static int ggm3d_batch_impl(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
-                            void *stream) {
+                            void *range_ws, size_t range_ws_bytes, void *stream) {
     GN_REQUIRE(batch >= 0 && batch <= 65535 && n0 > 0 && n1 > 0 && n2 > 0 && sigma > 0, "gn_ggm3d: bad sizes");
     GN_REQUIRE(accum_bits == 64 || accum_bits == 32, "gn_ggm3d: accum_bits must be 64 (scipy's arithmetic, bit for bit) or 32");
     const int radius = (int)(4.0 * sigma + 0.5);
@@ -373,20 +389,21 @@ static int ggm3d_batch_impl(const float *vol, int batch, int n0, int n1, int n2,
     float *t1 = tmp, *t2 = tmp + (int64_t)batch * tot;
     hipStream_t st = gn_stream(stream);
     if (radius <= GGM_R) {                          // one fused launch (tmp is not touched)
-        const dim3 grid((unsigned)(gn_cdiv(n0, GGM_TZ) * gn_cdiv(n1, GGM_TY) * gn_cdiv(n2, GGM_TX)), (unsigned)batch);
-        unsigned *enc = reinterpret_cast<unsigned *>(range2);
-        if (range2) hipLaunchKernelGGL(minmax_init_kernel, dim3(batch), dim3(1), 0, st, enc);
+        const dim3 grid((unsigned)ggm_tiles(n0, n1, n2), (unsigned)batch);
+        GN_REQUIRE(range2 == nullptr || (range_ws != nullptr && range_ws_bytes >= gn_ggm3d_range_workspace_bytes(batch, n0, n1, n2)),
+                   "gn_ggm3d_batch_ex: range_ws needs gn_ggm3d_range_workspace_bytes() bytes");
+        float *ws = reinterpret_cast<float *>(range_ws);
         if (accum_bits == 64) {
-            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<double, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, enc);
-            else hipLaunchKernelGGL((ggm_fused_kernel<double, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, enc);
+            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<double, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, ws);
+            else hipLaunchKernelGGL((ggm_fused_kernel<double, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, w0, w1, ws);
         } else {
             GgmW<float> f0, f1;
             for (int i = 0; i < 65; ++i) { f0.w[i] = (float)w0.w[i]; f1.w[i] = (float)w1.w[i]; }
             f0.radius = w0.radius; f0.symmetric = w0.symmetric; f1.radius = w1.radius; f1.symmetric = w1.symmetric;
-            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<float, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, enc);
-            else hipLaunchKernelGGL((ggm_fused_kernel<float, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, enc);
+            if (range2) hipLaunchKernelGGL((ggm_fused_kernel<float, true>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, ws);
+            else hipLaunchKernelGGL((ggm_fused_kernel<float, false>), grid, dim3(256), 0, st, vol, out, n0, n1, n2, f0, f1, ws);
         }
-        if (range2) hipLaunchKernelGGL(minmax_decode_kernel, dim3(batch), dim3(1), 0, st, enc);
+        if (range2) hipLaunchKernelGGL(ggm_range_reduce_kernel, dim3(batch), dim3(256), 0, st, reinterpret_cast<const float2 *>(ws), (int)(grid.x * 4), range2);
         GN_LAUNCH_CHECK("gn_ggm3d");
         return GN_OK;
     }
@@ -407,12 +424,12 @@ static int ggm3d_batch_impl(const float *vol, int batch, int n0, int n1, int n2,
 }
 
 extern "C" int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {
-    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, 64, nullptr, stream);
+    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, 64, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int gn_ggm3d_batch_ex(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
-                                 void *stream) {
-    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, accum_bits, range2, stream);
+                                 void *range_ws, size_t range_ws_bytes, void *stream) {
+    return ggm3d_batch_impl(vol, batch, n0, n1, n2, sigma, tmp, out, accum_bits, range2, range_ws, range_ws_bytes, stream);
 }
 
 extern "C" int gn_ggm3d(const float *vol, int n0, int n1, int n2, double sigma, float *tmp, float *out, void *stream) {

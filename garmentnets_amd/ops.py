@@ -784,7 +784,9 @@ def ggm3d_batch_range(vols, sigma, accum_bits=64):
     tmp = _ggm_tmp(vols.shape, sigma, vols.device)
     out = torch.empty_like(vols)
     rng = torch.empty((B, 2), dtype=torch.float32, device=vols.device)
-    _lib.call("gn_ggm3d_batch_ex", _p(vols), B, n0, n1, n2, float(sigma), _p(tmp), _p(out), int(accum_bits), _p(rng), _stream())
+    nws = _lib.load().gn_ggm3d_range_workspace_bytes(B, n0, n1, n2)             # a (min, max) pair per wave of the fused launch; scratch
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=vols.device)
+    _lib.call("gn_ggm3d_batch_ex", _p(vols), B, n0, n1, n2, float(sigma), _p(tmp), _p(out), int(accum_bits), _p(rng), _p(ws), nws, _stream())
     return out, rng
 
 

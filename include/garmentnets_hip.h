@@ -343,12 +343,14 @@ int gn_ggm3d_batch(const float *vol, int batch, int n0, int n1, int n2, double s
 int gn_minmax_batch(const float *x, int batch, int64_t n, float *out2, void *stream);
 /* gn_ggm3d_batch with two options (round 6; predict.py:160-171 needs the volume's range next to its gradient magnitude):
  *   range2 != NULL  [batch][2]: (min, max) of every volume, NaN-propagating, computed from the values the fused launch stages anyway (its tiles and
- *                   edge-replicated halos are voxels of the volume) -- no pass of its own over the volume, equal to gn_minmax_batch bit for bit;
- *                   a kernel radius above 2 (8-pass form) calls gn_minmax_batch.
+ *                   edge-replicated halos are voxels of the volume): every wave leaves one pair in range_ws (gn_ggm3d_range_workspace_bytes() bytes, contents
+ *                   scratch), a one-workgroup-per-volume launch folds them -- no pass of its own over the volume, no atomics, equal to gn_minmax_batch bit
+ *                   for bit; a kernel radius above 2 (8-pass form) calls gn_minmax_batch and ignores range_ws.
  *   accum_bits      64: scipy's arithmetic (fp64 taps), bit for bit, = gn_ggm3d_batch.  32: the same operation order accumulated in fp32 (fused form
  *                   only): 1e-6-class against scipy, not bit-compatible -- an opt-in for callers that hold floats to a tolerance. */
+size_t gn_ggm3d_range_workspace_bytes(int batch, int n0, int n1, int n2);
 int gn_ggm3d_batch_ex(const float *vol, int batch, int n0, int n1, int n2, double sigma, float *tmp, float *out, int accum_bits, float *range2,
-                      void *stream);
+                      void *range_ws, size_t range_ws_bytes, void *stream);
 
 /* Lewiner marching cubes (MC33).  replaces skimage.measure.marching_cubes(method='lewiner') -- predict.py:172-177.
  * gn_mc33_workspace_bytes: bytes of `ws` for a volume of n0*n1*n2.
