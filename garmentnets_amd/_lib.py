@@ -54,6 +54,7 @@ PROTOTYPES = {
     "gn_maxpool3d_2": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "gn_grid_stats": [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "gn_trilinear_sample": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i64, _i64, _vp, _i32, _vp],
+    "gn_trilinear_sample_batch": [_vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp],
     "gn_implicit_decode": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32,
                            _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp],
     "gn_ggm3d": [_vp, _i32, _i32, _i32, _f64, _vp, _vp, _vp],
@@ -75,6 +76,8 @@ PROTOTYPES = {
     "gn_mesh_compact": [_vp, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp],
     "gn_scale_verts": [_vp, _i64, _f64, _vp, _vp],
     "gn_implicit_decode_split": [_vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_implicit_decode_split_batch": [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "gn_implicit_decode_batch": [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp],
     "gn_implicit_decode_lattice_split": [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "gn_decoder_input_scale": [_vp, _i64, _i32, _i32, _f32, _vp, _vp],
     "gn_nearest_neighbor": [_vp, _i64, _vp, _i64, _vp, _vp, _vp],

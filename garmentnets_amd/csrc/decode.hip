@@ -91,7 +91,11 @@ __device__ __forceinline__ void tri_query(const float *__restrict__ vol, int D, 
 #define TRI_QPW 8
 __global__ __launch_bounds__(256) void trilinear_kernel(const float *__restrict__ vol, int D, int H, int W, int C,
                                                         const float *__restrict__ query, int Q, int64_t m0, int64_t M,
-                                                        float *__restrict__ out, int ldo) {
+                                                        float *__restrict__ out, int ldo, int64_t vol_bs, int64_t out_bs) {
+    // blockIdx.y: one volume of a batch with its own M queries and M output rows (gn_trilinear_sample_batch; strides 0 for the single-volume call)
+    vol += (int64_t)blockIdx.y * vol_bs;
+    out += (int64_t)blockIdx.y * out_bs;
+    if (query) query += (int64_t)blockIdx.y * M * 3;
     const int lane = threadIdx.x & 63;
     const int64_t mb = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * TRI_QPW;
     const int lpq = C >> 2;   // lanes per query in 16-byte mode
@@ -248,8 +252,20 @@ extern "C" int gn_trilinear_sample(const float *vol, int D, int H, int W, int C,
         return GN_OK;
     }
     hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gn_cdiv(M, 4 * TRI_QPW)), dim3(256), 0, gn_stream(stream), vol, D, H, W, C, query, Q, m0, M,
-                       out, ldo);
+                       out, ldo, (int64_t)0, (int64_t)0);
     GN_LAUNCH_CHECK("gn_trilinear_sample");
+    return GN_OK;
+}
+
+extern "C" int gn_trilinear_sample_batch(const float *vol, int B, int64_t vol_bstride, int D, int H, int W, int C, const float *query, int64_t M, float *out,
+                                         int ldo, void *stream) {
+    GN_REQUIRE(B >= 0 && B <= 65535 && D > 0 && H > 0 && W > 0 && C > 0 && M >= 0 && ldo >= C, "gn_trilinear_sample_batch: bad sizes");
+    GN_REQUIRE((C & 1) || (ldo % 2 == 0), "gn_trilinear_sample_batch: even channel counts need an even output leading dimension");
+    if (M == 0 || B == 0) return GN_OK;
+    GN_REQUIRE(query != nullptr && vol != nullptr && out != nullptr, "gn_trilinear_sample_batch: null pointer");
+    hipLaunchKernelGGL(trilinear_kernel, dim3((unsigned)gn_cdiv(M, 4 * TRI_QPW), (unsigned)B), dim3(256), 0, gn_stream(stream), vol, D, H, W, C, query, 0,
+                       (int64_t)0, M, out, ldo, vol_bstride, M * (int64_t)ldo);
+    GN_LAUNCH_CHECK("gn_trilinear_sample_batch");
     return GN_OK;
 }
 
@@ -275,6 +291,7 @@ struct DecodeArgs {
     const float *w3, *b3, *s3, *t3; int OUT;
     float *out; int ldo;
     const float *run_if;                  // NULL, or a device flag: the kernel does nothing unless *run_if != 0
+    long long xin_bs, out_bs; int run_if_bs;   // blockIdx.y: one row set of a batch (gn_implicit_decode_batch); 0 for the single call
 };
 
 #define DEC_TM 32
@@ -397,7 +414,9 @@ template <int OUTC>
 __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (p.run_if && *p.run_if == 0.f) return;       // gated launch (the split-operand kernel handled these rows)
+    if (p.run_if && p.run_if[(long long)blockIdx.y * p.run_if_bs] == 0.f) return;       // gated launch (the split-operand kernel handled these rows)
+    if (p.xin) p.xin += (long long)blockIdx.y * p.xin_bs;
+    p.out += (long long)blockIdx.y * p.out_bs;
     const int ldp = p.C0 + 4, ldq = p.N1 + 4;
     float *P = dsm, *Qb = dsm + DEC_TM * ldp, *red = Qb + DEC_TM * ldq;   // X0 | H1 | 8 x 32 x OUT partial dot products
     // a bounded grid walking the row tiles (round 6): a GATED launch that has nothing to do (the common case: the split-operand kernel handled the rows)
@@ -471,10 +490,10 @@ __global__ __launch_bounds__(256, 3) void implicit_decode_kernel(DecodeArgs p) {
     }
 }
 
-extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
-                                  const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
-                                  const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
-                                  const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, void *stream) {
+static int implicit_decode_impl(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
+                                const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
+                                const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                                const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, int B, int run_if_bs, void *stream) {
     GN_REQUIRE((xin != nullptr || (vol != nullptr && D > 0 && H > 0 && W > 0)) && M >= 0 && ldo >= OUT, "gn_implicit_decode: bad sizes");
     if (M == 0) return GN_OK;
     GN_REQUIRE(xin == nullptr || (ldxin >= C0 && ldxin % 4 == 0), "gn_implicit_decode: pre-sampled rows need a 16-byte aligned leading dimension");
@@ -488,14 +507,15 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
     p.vol = vol; p.D = D; p.H = H; p.W = W; p.C0 = C0; p.xin = xin; p.ldxin = ldxin; p.query = query; p.Q = Q; p.m0 = m0; p.M = M;
     p.w1p = w1p; p.b1 = b1; p.s1 = s1; p.t1 = t1; p.N1 = N1; p.w2p = w2p; p.b2 = b2; p.s2 = s2; p.t2 = t2; p.N2 = N2;
     p.w3 = w3; p.b3 = b3; p.s3 = s3; p.t3 = t3; p.OUT = OUT; p.out = out; p.ldo = ldo; p.run_if = run_if;
+    p.xin_bs = B > 1 ? M * (long long)ldxin : 0; p.out_bs = B > 1 ? M * (long long)ldo : 0; p.run_if_bs = B > 1 ? run_if_bs : 0;
     const int ldp = C0 + 4, ldq = N1 + 4;
     const size_t sh = sizeof(float) * DEC_TM * (size_t)(ldp + ldq + 8 * OUT);
     GN_REQUIRE(sh <= 160 * 1024, "gn_implicit_decode: layer widths need %zu bytes of LDS", sh);
-    const int64_t tiles = gn_cdiv(M, DEC_TM);
+    const int64_t tiles = gn_cdiv(M, DEC_TM), gcap = B > 1 ? (DEC_MAX_GRID / B > 0 ? DEC_MAX_GRID / B : 1) : DEC_MAX_GRID;
 #define DEC_LAUNCH(O)                                                                                                                  \
     do {                                                                                                                               \
         GN_HIP(hipFuncSetAttribute((const void *)implicit_decode_kernel<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh), "gn_implicit_decode"); \
-        hipLaunchKernelGGL(implicit_decode_kernel<O>, dim3((unsigned)(tiles < DEC_MAX_GRID ? tiles : DEC_MAX_GRID)), dim3(256), sh, gn_stream(stream), p); \
+        hipLaunchKernelGGL(implicit_decode_kernel<O>, dim3((unsigned)(tiles < gcap ? tiles : gcap), (unsigned)B), dim3(256), sh, gn_stream(stream), p); \
     } while (0)
     switch (OUT) {
         case 1: DEC_LAUNCH(1); break;
@@ -506,4 +526,23 @@ extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0,
 #undef DEC_LAUNCH
     GN_LAUNCH_CHECK("gn_implicit_decode");
     return GN_OK;
+}
+
+extern "C" int gn_implicit_decode(const float *vol, int D, int H, int W, int C0, const float *xin, int ldxin, const float *query, int Q, int64_t m0, int64_t M,
+                                  const float *w1p, const float *b1, const float *s1, const float *t1, int N1, const float *w2p,
+                                  const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                                  const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, void *stream) {
+    return implicit_decode_impl(vol, D, H, W, C0, xin, ldxin, query, Q, m0, M, w1p, b1, s1, t1, N1, w2p, b2, s2, t2, N2, w3, b3, s3, t3, OUT, out, ldo, run_if, 1, 0,
+                                stream);
+}
+
+// B row sets of M pre-sampled rows each through one launch (blockIdx.y = row set): xin [B][M][ldxin], out [B][M][ldo], run_if NULL or one flag per row
+// set at run_if[b * run_if_stride] (the gated fp32 twin of gn_implicit_decode_split_batch: run_if = xscale + 2, stride 4)
+extern "C" int gn_implicit_decode_batch(const float *xin, int ldxin, int64_t M, int B, int C0, const float *w1p, const float *b1, const float *s1, const float *t1,
+                                        int N1, const float *w2p, const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                                        const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, int run_if_stride, void *stream) {
+    GN_REQUIRE(B >= 0 && B <= 65535 && xin != nullptr, "gn_implicit_decode_batch: bad sizes");
+    if (B == 0) return GN_OK;
+    return implicit_decode_impl(nullptr, 0, 0, 0, C0, xin, ldxin, nullptr, 0, 0, M, w1p, b1, s1, t1, N1, w2p, b2, s2, t2, N2, w3, b3, s3, t3, OUT, out, ldo, run_if, B,
+                                run_if_stride, stream);
 }

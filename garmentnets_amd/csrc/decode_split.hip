@@ -52,6 +52,9 @@ struct DecSplitArgs {
     // lattice form (LAT): the rows are not read from xin but sampled here -- lattice point m0 + m of the (Q,Q,Q) grid of predict.py:145-147 from
     // the channel-last volume vol [D][H][W][32] (trilinear, border, align_corners: the arithmetic of decode.hip, bit for bit)
     const float *vol; int D, H, W, Q; long long m0;
+    // blockIdx.y: one row set of a batch (gn_implicit_decode_split_batch: the surface queries of every garment of a batch in ONE launch) with its own rows,
+    // outputs and input scale; strides 0 / grid.y 1 for the single call
+    long long xin_bs, out_bs; int xscale_bs;
 };
 
 // ---- lattice sampling (LAT).  A lane owns 16 channels of its query: 8h..8h+7 and 16+8h..16+8h+7 = four float4 per corner.
@@ -184,6 +187,9 @@ __global__ __launch_bounds__(256, (K0G <= 2 && OUTC == 1) ? 2 : 1) void implicit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
 
+    if (p.xin) p.xin += (long long)blockIdx.y * p.xin_bs;
+    p.out += (long long)blockIdx.y * p.out_bs;
+    if (p.xscale) p.xscale += (long long)blockIdx.y * p.xscale_bs;
     if (p.xscale && p.xscale[2] != 0.f) return;     // wave-uniform: the whole grid leaves (gn_decoder_input_scale's verdict)
     const float sx = p.xscale ? p.xscale[0] : 1.f, inv_sx = p.xscale ? p.xscale[1] : 1.f;
     // the bias entries (all of tab1, row 0 of every tab2 block) enter in the scaled units of the chain
@@ -473,6 +479,9 @@ __global__ __launch_bounds__(256, 1) void implicit_decode_split512_kernel(DecSpl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long ntiles = (p.M + DS_TILE - 1) / DS_TILE;
 
+    if (p.xin) p.xin += (long long)blockIdx.y * p.xin_bs;
+    p.out += (long long)blockIdx.y * p.out_bs;
+    if (p.xscale) p.xscale += (long long)blockIdx.y * p.xscale_bs;
     if (p.xscale && p.xscale[2] != 0.f) return;     // wave-uniform: the whole grid leaves (gn_decoder_input_scale's verdict)
     const float sx = p.xscale ? p.xscale[0] : 1.f, inv_sx = p.xscale ? p.xscale[1] : 1.f;
     for (int i = tid; i < TABN; i += 256) {          // the bias entries enter in the scaled units of the chain
@@ -691,7 +700,7 @@ extern "C" int gn_implicit_decode_lattice_split(const float *vol, int D, int H, 
     GN_REQUIRE(((uintptr_t)vol & 15) == 0, "gn_implicit_decode_lattice_split: the volume must be 16-byte aligned");
     DecSplitArgs p;
     p.xin = nullptr; p.ldxin = 0; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.xscale = xscale; p.out = out; p.ldo = ldo;
-    p.vol = vol; p.D = D; p.H = H; p.W = W; p.Q = Q; p.m0 = m0;
+    p.vol = vol; p.D = D; p.H = H; p.W = W; p.Q = Q; p.m0 = m0; p.xin_bs = p.out_bs = 0; p.xscale_bs = 0;
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
     const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
     hipLaunchKernelGGL((implicit_decode_split_kernel<1, 2, true>), dim3(grid), dim3(256), 0, gn_stream(stream), p);
@@ -699,37 +708,40 @@ extern "C" int gn_implicit_decode_lattice_split(const float *vol, int D, int H, 
     return GN_OK;
 }
 
-extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
-                                        int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
-    GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4, "gn_implicit_decode_split: bad sizes");
+static int implicit_decode_split_impl(const float *xin, int ldxin, int64_t M, int B, const void *wpack, const float *tab, const float *xscale,
+                                      int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
+    GN_REQUIRE(M >= 0 && ldo >= OUT && OUT >= 1 && OUT <= 4 && B >= 0 && B <= 65535, "gn_implicit_decode_split: bad sizes");
     const bool wide512 = C0 == 32 && N1 == 512 && N2 == 512;
     GN_REQUIRE(wide512 || ((C0 == 128 || C0 == 32) && N1 == DS_N && N2 == DS_N),
                "gn_implicit_decode_split: only [128 | 32, 256, 256, out] and [32, 512, 512, out] decoders are packed for this kernel (got [%d,%d,%d,%d])", C0, N1, N2, OUT);
     GN_REQUIRE(ldxin >= C0 && ldxin % 4 == 0, "gn_implicit_decode_split: rows need a 16-byte aligned leading dimension");
-    if (M == 0) return GN_OK;
+    if (M == 0 || B == 0) return GN_OK;
     GN_REQUIRE(xin && wpack && tab && out, "gn_implicit_decode_split: null pointer");
     DecSplitArgs p;
     p.xin = xin; p.ldxin = ldxin; p.M = M; p.wp = (const unsigned char *)wpack; p.tab = tab; p.xscale = xscale; p.out = out; p.ldo = ldo;
     p.vol = nullptr; p.D = p.H = p.W = p.Q = 0; p.m0 = 0;
+    p.xin_bs = B > 1 ? M * (long long)ldxin : 0; p.out_bs = B > 1 ? M * (long long)ldo : 0; p.xscale_bs = B > 1 ? 4 : 0;
     const int64_t ntiles = gn_cdiv(M, DS_TILE);
-    const int64_t slots = (C0 == 32 && OUT == 1) ? 512 : 256;                       // persistent workgroups: two per CU when they fit (K0G = 2), else one
-    const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    // persistent workgroups: two per CU when they fit (K0G = 2), else one; a batch shares the slots between its row sets (grid.y)
+    const int64_t slots0 = (C0 == 32 && OUT == 1) ? 512 : 256, slots = slots0 / B > 0 ? slots0 / B : 1;
+    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots), (unsigned)B);
     hipStream_t st = gn_stream(stream);
     if (wide512) {
-        const unsigned g512 = (unsigned)(ntiles < 256 ? ntiles : 256);
+        const int64_t s512 = 256 / B > 0 ? 256 / B : 1;
+        const dim3 g512((unsigned)(ntiles < s512 ? ntiles : s512), (unsigned)B);
         switch (OUT) {
-            case 1: hipLaunchKernelGGL((implicit_decode_split512_kernel<1>), dim3(g512), dim3(256), 0, st, p); break;
-            case 2: hipLaunchKernelGGL((implicit_decode_split512_kernel<2>), dim3(g512), dim3(256), 0, st, p); break;
-            case 3: hipLaunchKernelGGL((implicit_decode_split512_kernel<3>), dim3(g512), dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((implicit_decode_split512_kernel<4>), dim3(g512), dim3(256), 0, st, p); break;
+            case 1: hipLaunchKernelGGL((implicit_decode_split512_kernel<1>), g512, dim3(256), 0, st, p); break;
+            case 2: hipLaunchKernelGGL((implicit_decode_split512_kernel<2>), g512, dim3(256), 0, st, p); break;
+            case 3: hipLaunchKernelGGL((implicit_decode_split512_kernel<3>), g512, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((implicit_decode_split512_kernel<4>), g512, dim3(256), 0, st, p); break;
         }
         GN_LAUNCH_CHECK("gn_implicit_decode_split");
         return GN_OK;
     }
 #define DS_LAUNCH(O)                                                                                                           \
     do {                                                                                                                       \
-        if (C0 == 128) hipLaunchKernelGGL((implicit_decode_split_kernel<O, 8>), dim3(grid), dim3(256), 0, st, p);              \
-        else hipLaunchKernelGGL((implicit_decode_split_kernel<O, 2>), dim3(grid), dim3(256), 0, st, p);                        \
+        if (C0 == 128) hipLaunchKernelGGL((implicit_decode_split_kernel<O, 8>), grid, dim3(256), 0, st, p);                    \
+        else hipLaunchKernelGGL((implicit_decode_split_kernel<O, 2>), grid, dim3(256), 0, st, p);                              \
     } while (0)
     switch (OUT) {
         case 1: DS_LAUNCH(1); break;
@@ -740,4 +752,17 @@ extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, 
 #undef DS_LAUNCH
     GN_LAUNCH_CHECK("gn_implicit_decode_split");
     return GN_OK;
+}
+
+extern "C" int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
+                                        int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
+    return implicit_decode_split_impl(xin, ldxin, M, 1, wpack, tab, xscale, C0, N1, N2, OUT, out, ldo, stream);
+}
+
+// B row sets of M rows each in ONE launch (blockIdx.y = row set): xin [B][M][ldxin], out [B][M][ldo], xscale NULL or [B][4] (row set b's input scale record
+// of gn_decoder_input_scale; a set marked unsafe is left to gn_implicit_decode_batch(run_if = xscale + 2, stride 4)).  What the surface decoders of
+// predict.py:184-187 need for a batch: 16 launches of 384 tiles on 256 persistent workgroups (1.5 rounds each) become one of 6144 tiles (24 rounds).
+extern "C" int gn_implicit_decode_split_batch(const float *xin, int ldxin, int64_t M, int B, const void *wpack, const float *tab, const float *xscale,
+                                              int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream) {
+    return implicit_decode_split_impl(xin, ldxin, M, B, wpack, tab, xscale, C0, N1, N2, OUT, out, ldo, stream);
 }

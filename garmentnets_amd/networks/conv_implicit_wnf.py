@@ -231,6 +231,24 @@ class ImplicitWNFDecoder(PackedModule):
             else:
                 out[m0:m0 + m] = self.mlp(s)
 
+    # queries of a whole batch in one set of launches when their sampled rows fit the cache they are handed over in (the surface decoders of
+    # predict.py:184-187: 16 x ~49 000 vertices x 32 channels = 100 MB); larger query sets (and the lattice) go garment by garment in 1 M-row chunks
+    BATCH_ROWS_BYTES = int(os.environ.get("GARMENTNETS_DECODE_BATCH_BYTES", 192 << 20))
+
+    def _decode_queries_batched(self, vol, q, out, layers, xs, arith):
+        """vol (B,D,H,W,C) channel-last, q (B,M,3), out (B,M,OUT) through the split-operand decoder in three launches for the whole batch (sampler, decoder,
+        gated fp32 twin); -> False when this path does not apply (the caller loops over the garments: same results row for row)"""
+        B, M = q.shape[:2]
+        C = vol.shape[-1]
+        if (B < 2 or M == 0 or layers is None or layers[3] is None or arith.decode_mode != "f16x2" or not vol.is_contiguous()
+                or B * M * ops.pad4(C) * 4 > self.BATCH_ROWS_BYTES or out.stride(0) != M * out.stride(1)):
+            return False
+        rows = ops.trilinear_sample_batch(vol, q)
+        ops.implicit_decode_split_batch(rows, layers[3], out, xscale=xs)
+        if xs is not None:                  # the garments the device marked unsafe for fp16 planes: gated fp32 twin (a no-op otherwise)
+            ops.implicit_decode_batch(rows, layers[:3], out, run_if=xs[:, 2:], run_if_stride=xs.stride(0))
+        return True
+
     def forward(self, features_grid, query_points, arith=None):
         """features_grid (B,C,D,H,W), query_points (B,M,3) in [0,1] -> (B,M,out)"""
         arith = arith or self.arith or AR.DEFAULT
@@ -239,6 +257,8 @@ class ImplicitWNFDecoder(PackedModule):
         q = query_points.float().contiguous()
         out = torch.empty((B, M, self.out_channels), dtype=torch.float32, device=vol.device)
         xs = self._volume_scales(features_grid, vol, arith)
+        if self._decode_queries_batched(vol, q, out, self.packed() if self.fused else None, xs, arith):
+            return out
         for b in range(B):
             self._decode_rows(vol[b], out[b], query=q[b], xscale=None if xs is None else xs[b], arith=arith)
         return out
@@ -295,6 +315,8 @@ class ImplicitWNFDecoder(PackedModule):
             return out.reshape(B, Q, Q, Q, self.out_channels).squeeze(-1)
         q = query_points.float().contiguous()
         out = torch.empty((B, q.shape[1], self.out_channels), dtype=torch.float32, device=vol.device)
+        if self._decode_queries_batched(vol, q, out, layers, xs, arith):
+            return out
         for b in range(B):
             self._decode_rows(vol[b], out[b], query=q[b], layers=layers, xscale=None if xs is None else xs[b], arith=arith)
         return out

@@ -632,6 +632,38 @@ def implicit_decode(vol_b, layers, query=None, Q=0, m0=0, M=None, out=None, xin=
     return out
 
 
+def trilinear_sample_batch(vol, query, out=None):
+    """vol (B, D, H, W, C) channel-last, query (B, M, 3) -> rows (B, M, C) [leading dimension padded to 4]: every volume's queries in one launch"""
+    B, D, H, W, C = vol.shape
+    M = query.shape[1]
+    _chk(vol, torch.float32, "vol")
+    _chk(query, torch.float32, "query")
+    if out is None:
+        out = torch.empty((B, M, pad4(C)), dtype=torch.float32, device=vol.device)[:, :, :C]
+    _lib.call("gn_trilinear_sample_batch", _p(vol), B, vol.stride(0), D, H, W, C, _p(query), int(M), _p(out), out.stride(1), _stream())
+    return out
+
+
+def implicit_decode_batch(xin, layers, out, run_if=None, run_if_stride=0):
+    """implicit_decode(xin=...) for B row sets in one launch: xin (B, M, C0) [row stride = leading dimension], out (B, M, OUT); run_if: one device flag per
+    row set at run_if[b * run_if_stride] (the gated fp32 twin of implicit_decode_split_batch)"""
+    (w1p, b1, s1, t1, N1), (w2p, b2, s2, t2, N2), (w3, b3, s3, t3, OUT) = layers
+    B, M, C0 = xin.shape
+    _lib.call("gn_implicit_decode_batch", _p(xin), xin.stride(1), int(M), B, C0, _p(w1p), _p(b1), _p(s1), _p(t1), N1, _p(w2p), _p(b2), _p(s2), _p(t2), N2,
+              _p(w3), _p(b3), _p(s3), _p(t3), OUT, _p(out), out.stride(1), _p(run_if), int(run_if_stride), _stream())
+    return out
+
+
+def implicit_decode_split_batch(xin, pack, out, xscale=None):
+    """implicit_decode_split for B row sets in ONE launch: xin (B, M, C0), out (B, M, OUT), xscale None or (B, 4) -- row set b with its own input scale
+    record; row for row the results of the single call (the persistent workgroups are shared between the sets through blockIdx.y)"""
+    B, M, C0 = xin.shape
+    assert xin.stride(0) == M * xin.stride(1) and out.stride(0) == M * out.stride(1), "row sets must be packed back to back"
+    _lib.call("gn_implicit_decode_split_batch", _p(xin), xin.stride(1), int(M), B, _p(pack.wpack), _p(pack.tab), _p(xscale),
+              C0, pack.hidden, pack.hidden, pack.out_channels, _p(out), out.stride(1), _stream())
+    return out
+
+
 class DecodeSplitPack:
     """weights / epilogue tables of gn_implicit_decode_split for one [128 | 32, 256, 256, OUT] decoder; smax: upper bound for the run-time
     input scale (keeps the scaled biases small, see pack_decode_split)"""

@@ -310,6 +310,10 @@ int gn_maxpool3d_2(const float *in, int B, int D, int H, int W, int C, float *ou
  * q[i][j][k] = (i,j,k) * (1/(Q-1)), rows m0..m0+M of the flattened (Q,Q,Q) lattice. */
 int gn_trilinear_sample(const float *vol, int D, int H, int W, int C, const float *query, int Q, int64_t m0, int64_t M,
                         float *out, int ldo, void *stream);
+/* the query form for B volumes in one launch (round 6; the surface decoders of predict.py:184-187 for a whole batch): volume b = vol + b * vol_bstride
+ * floats, its M queries query [b][M][3], its rows out [b][M][ldo]. */
+int gn_trilinear_sample_batch(const float *vol, int B, int64_t vol_bstride, int D, int H, int W, int C, const float *query, int64_t M, float *out, int ldo,
+                              void *stream);
 
 /* Fused implicit decoder: trilinear sampling (as gn_trilinear_sample) + the 3-layer MLP of ImplicitWNFDecoder
  * (Linear -> ReLU -> BatchNorm1d per layer, widths [C0, N1, N2, OUT]) in one kernel -- networks/conv_implicit_wnf.py:128-149,
@@ -415,6 +419,14 @@ int gn_mesh_largest_component(const int32_t *faces, int64_t F, int64_t V, void *
  * replaces the three Linear/ReLU/BatchNorm1d blocks of ImplicitWNFDecoder.forward -- networks/conv_implicit_wnf.py:128-149. */
 int gn_implicit_decode_split(const float *xin, int ldxin, int64_t M, const void *wpack, const float *tab, const float *xscale,
                              int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream);
+/* B row sets of M rows each in ONE launch (round 6): xin [B][M][ldxin], out [B][M][ldo], xscale NULL or [B][4] (one gn_decoder_input_scale record per row set;
+ * a set marked unsafe is skipped and left to gn_implicit_decode_batch(run_if = xscale + 2, run_if_stride = 4)).  Row for row the single call's results. */
+int gn_implicit_decode_split_batch(const float *xin, int ldxin, int64_t M, int B, const void *wpack, const float *tab, const float *xscale,
+                                   int C0, int N1, int N2, int OUT, float *out, int ldo, void *stream);
+/* gn_implicit_decode on B sets of M pre-sampled rows (the gated fp32 twin of the call above): run_if NULL or one flag per row set at run_if[b * run_if_stride]. */
+int gn_implicit_decode_batch(const float *xin, int ldxin, int64_t M, int B, int C0, const float *w1p, const float *b1, const float *s1, const float *t1,
+                             int N1, const float *w2p, const float *b2, const float *s2, const float *t2, int N2, const float *w3, const float *b3,
+                             const float *s3, const float *t3, int OUT, float *out, int ldo, const float *run_if, int run_if_stride, void *stream);
 
 /* gn_implicit_decode_split with the lattice sampler INSIDE the decoder kernel (reference call site
  * networks/conv_implicit_wnf.py:137-149 under the lattice loop of predict.py:145-157): rows m0 .. m0+M-1 of the (Q,Q,Q) lattice are sampled

@@ -332,7 +332,16 @@ def test_surface_decoder_nan_triggers_the_fp32_rerun(monkeypatch):
                 r[0] = float("nan")
                 state["armed"] = False
             return r
+        orig_b = ops.implicit_decode_split_batch
+
+        def poisoned_batch(xin, pack, out, xscale=None, _which=which):       # (round 6: a batch's surface queries go through the batched entry)
+            r = orig_b(xin, pack, out, xscale=xscale)
+            if state["armed"] and pack.out_channels == _which:
+                r[0, 0] = float("nan")
+                state["armed"] = False
+            return r
         monkeypatch.setattr(ops, "implicit_decode_split", poisoned)
+        monkeypatch.setattr(ops, "implicit_decode_split_batch", poisoned_batch)
         for runner in ("batch", "job"):
             state["armed"] = True
             PR._FALLBACKS["count"] = 0
@@ -346,6 +355,7 @@ def test_surface_decoder_nan_triggers_the_fp32_rerun(monkeypatch):
                 assert torch.equal(a["warp_field"], b["warp_field"]) and torch.equal(a["is_on_surface_logits"], b["is_on_surface_logits"])
                 assert torch.equal(a["wnf_volume"], b["wnf_volume"]) and torch.equal(a["faces"], b["faces"])
         monkeypatch.setattr(ops, "implicit_decode_split", orig)
+        monkeypatch.setattr(ops, "implicit_decode_split_batch", orig_b)
 
 
 def test_decoder_input_scale_is_not_keyed_on_a_recycled_address():

@@ -268,6 +268,17 @@ def test_pipeline_against_reference_goldens(golden_dir, name):
     sq = torch.from_numpy(g["surf_query"]).to(DEV)
     np.testing.assert_allclose(model.surface_decoder_forward(u3, sq)["out_features"].cpu().numpy(), g["surf_out"], rtol=0, atol=TOL)
     np.testing.assert_allclose(model.volume_decoder_forward(u3, sq)["pred_volume_value"].cpu().numpy(), g["volq_out"], rtol=0, atol=TOL)
+    if B > 1:       # round 6: a batch's queries go through three launches (one row set per blockIdx.y) -- bit for bit what the garment loop gives
+        q3 = torch.rand(B, 1500, 3, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        for dec_name, fwd, key in (("surface_decoder", model.surface_decoder_forward, "out_features"), ("volume_decoder", model.volume_decoder_forward, "pred_volume_value")):
+            dec = getattr(model, dec_name)
+            batched = fwd(u3, q3)[key]
+            dec.BATCH_ROWS_BYTES = 0                  # (instance attribute: forces the loop)
+            try:
+                looped = fwd(u3, q3)[key]
+            finally:
+                del dec.BATCH_ROWS_BYTES
+            assert torch.equal(batched, looped), dec_name
     # the reference's own chunked query loop (predict.py:145-157) through the API-compatible path gives the same volume
     from garmentnets_amd.components.gridding import ArraySlicer, VirtualGrid
     gp = VirtualGrid(grid_shape=(Q,) * 3).get_grid_points(include_batch=False)
@@ -1206,6 +1217,41 @@ def test_decoder_split_range_contract(case, k0):
     e16, e32 = ((out - h).abs().amax(dim=0) / scale).max().item(), ((out32 - h).abs().amax(dim=0) / scale).max().item()
     print(f"decoder [{k0},256,256,3] {case}: input scale 2^{float(torch.log2(xs[0, 0])):.0f}{' (unsafe -> fp32 kernel)' if unsafe else ''}, rel err split {e16:.2e}, fp32-MFMA {e32:.2e}")
     assert torch.isfinite(out).all() and e16 <= max(2 * e32, 3e-6)
+
+
+@pytest.mark.parametrize("k0,out_ch,M", [(32, 3, 5000), (32, 1, 777), (128, 3, 1300)])
+def test_decoder_batch_entries_are_the_single_calls_row_for_row(k0, out_ch, M):
+    """gn_trilinear_sample_batch / gn_implicit_decode_split_batch / gn_implicit_decode_batch (round 6: the surface queries of a whole batch in three
+    launches, one row set per blockIdx.y) against the per-garment calls, bit for bit -- four row sets with input magnitudes from 1e-6 to 1e3, so that every
+    set has its own input scale and one of them is sent to the gated fp32 twin by the device; M not a multiple of the 128-query tile"""
+    g = torch.Generator().manual_seed(k0 + out_ch + M)
+    B, dims = 4, [k0, 256, 256, out_ch]
+    mags = [1.0, 1e3, 1e-6, 0.03]
+    vol = torch.stack([torch.relu(torch.randn(6, 7, 5, k0, generator=g)) * m for m in mags]).to(DEV)
+    q = torch.rand(B, M, 3, generator=g).to(DEV)
+    raw = []
+    for i in range(3):
+        w = torch.randn(dims[i + 1], dims[i], generator=g) * (2.0 / dims[i]) ** 0.5
+        raw.append((w, torch.randn(dims[i + 1], generator=g) * 0.1, torch.rand(dims[i + 1], generator=g) + 0.5, torch.randn(dims[i + 1], generator=g) * 0.1))
+    pack = ops.pack_decode_split(raw).to(DEV)
+    st = ops.channel_stats(vol)
+    xs = ops.decoder_input_scale(st[1], st[2], pack.smax)
+    assert len({float(v) for v in xs[:, 0]}) >= 3 and float(xs[:, 2].sum()) >= 1          # different scales; at least one unsafe set
+    layers = tuple((ops.pack_kpair(w).to(DEV) if i < 2 else w.contiguous().to(DEV), b.to(DEV), sc.to(DEV), sh.to(DEV), dims[i + 1]) for i, (w, b, sc, sh) in enumerate(raw))
+    rows = ops.trilinear_sample_batch(vol, q)
+    out = torch.full((B, M, out_ch), 7.0, dtype=torch.float32, device=DEV)
+    ops.implicit_decode_split_batch(rows, pack, out, xscale=xs)
+    ops.implicit_decode_batch(rows, layers[:3], out, run_if=xs[:, 2:], run_if_stride=xs.stride(0))
+    for b in range(B):
+        r1 = ops.trilinear_sample(vol[b], query=q[b])
+        assert torch.equal(rows[b], r1), b
+        o1 = ops.implicit_decode_split(r1, pack, xscale=xs[b])
+        ops.implicit_decode(None, layers, M=M, xin=r1, out=o1, run_if=xs[b, 2:3])
+        assert torch.equal(out[b], o1), b
+    assert torch.isfinite(out).all()
+    o2 = torch.empty_like(out)                              # without scale records: every set through the split kernel, unscaled
+    ops.implicit_decode_split_batch(rows[:2], pack, o2[:2])
+    assert torch.equal(o2[0], ops.implicit_decode_split(rows[0], pack)) and torch.equal(o2[1], ops.implicit_decode_split(rows[1], pack))
 
 
 def test_predict_falls_back_to_fp32_on_nan(monkeypatch):
