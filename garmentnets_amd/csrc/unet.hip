@@ -65,45 +65,55 @@ extern "C" int gn_channel_stats(const float *x, int B, int64_t V, int C, double 
 // in the conv epilogue.  fp16's narrow exponent then never matters: a channel's values are bounded by rms * sqrt(V) <= 2 * 2^14.5
 // < 65504 for any V < 2^29 voxels (no overflow by construction, whatever the checkpoint), and values down to 1/8 of the typical
 // magnitude keep a normal second plane (residual <= 2^-22 |x|; below that the residual is absolute, 2^-25 of the sample's scale).
-__global__ __launch_bounds__(64) void groupnorm_affine_kernel(const double *__restrict__ sum0, const double *__restrict__ sq0, int C0, int64_t V0,
+// Round 6: the statistics of the sample are first brought into LDS by all threads (coalesced), the per-GROUP sums are then formed by one thread per group
+// in ascending channel order -- the summation order of the round-1 kernel, bit for bit -- and everything per CHANNEL (a, d, the rms) runs one thread per
+// channel.  The thread-per-group form walked up to 48 channels through dependent global loads: 40 us for the 384-channel decoder layer, 12 us typical.
+#define GNA_THREADS 256
+#define GNA_MAXC 1024
+__global__ __launch_bounds__(GNA_THREADS) void groupnorm_affine_kernel(const double *__restrict__ sum0, const double *__restrict__ sq0, int C0, int64_t V0,
                                         const double *__restrict__ sum1, const double *__restrict__ sq1, int C1, int64_t V1,
                                         int rep1, int B, int groups, float eps, const float *__restrict__ gamma,
                                         const float *__restrict__ beta, float *__restrict__ a, float *__restrict__ d,
                                         float *__restrict__ act_inv_scale) {
-    __shared__ float gmax[64];
-    const int b = blockIdx.x, C = C0 + C1, cpg = C / groups;
-    float my_max = 0.f;
-    for (int g = threadIdx.x; g < groups; g += 64) {
+    __shared__ double ls[GNA_MAXC], lq[GNA_MAXC];           // per-channel sum / sum of squares (source 1 already times rep1)
+    __shared__ float grstd[GNA_MAXC], gmean[GNA_MAXC];      // per group
+    __shared__ float gmax[GNA_THREADS / 64];
+    const int b = blockIdx.x, C = C0 + C1, cpg = C / groups, tid = threadIdx.x;
+    for (int c = tid; c < C; c += GNA_THREADS) {
+        if (c < C0) { ls[c] = sum0[(int64_t)b * C0 + c]; lq[c] = sq0[(int64_t)b * C0 + c]; }
+        else { ls[c] = rep1 * sum1[(int64_t)b * C1 + c - C0]; lq[c] = rep1 * sq1[(int64_t)b * C1 + c - C0]; }
+    }
+    __syncthreads();
+    for (int g = tid; g < groups; g += GNA_THREADS) {
         double s = 0.0, q = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            if (c < C0) { s += sum0[(int64_t)b * C0 + c]; q += sq0[(int64_t)b * C0 + c]; }
-            else { s += rep1 * sum1[(int64_t)b * C1 + c - C0]; q += rep1 * sq1[(int64_t)b * C1 + c - C0]; }
-        }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += ls[c]; q += lq[c]; }
         const double n = (double)cpg * (double)V0;  // V0 == V1*rep1 voxels per channel after upsampling
         const double mean = s / n;
         double var = q / n - mean * mean;
         if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float fmean = (float)mean;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const float ga = gamma[c] * rstd;
-            const float dd = beta[c] - fmean * ga;
-            a[(int64_t)b * C + c] = ga;
-            d[(int64_t)b * C + c] = dd;
-            if (act_inv_scale) {
-                const double ex = (c < C0 ? sum0[(int64_t)b * C0 + c] : rep1 * sum1[(int64_t)b * C1 + c - C0]) / (double)V0;
-                const double ex2 = (c < C0 ? sq0[(int64_t)b * C0 + c] : rep1 * sq1[(int64_t)b * C1 + c - C0]) / (double)V0;
-                const double ey2 = (double)ga * ga * ex2 + 2.0 * (double)ga * dd * ex + (double)dd * dd;
-                const float rms = ey2 > 0 ? (float)sqrt(ey2) : 0.f;
-                if (rms > my_max) my_max = rms;          // (a NaN statistic compares false: the scale stays finite and the NaN reaches the output)
-            }
+        grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        gmean[g] = (float)mean;
+    }
+    __syncthreads();
+    float my_max = 0.f;
+    for (int c = tid; c < C; c += GNA_THREADS) {
+        const int g = c / cpg;
+        const float ga = gamma[c] * grstd[g];
+        const float dd = beta[c] - gmean[g] * ga;
+        a[(int64_t)b * C + c] = ga;
+        d[(int64_t)b * C + c] = dd;
+        if (act_inv_scale) {
+            const double ex = ls[c] / (double)V0, ex2 = lq[c] / (double)V0;
+            const double ey2 = (double)ga * ga * ex2 + 2.0 * (double)ga * dd * ex + (double)dd * dd;
+            const float rms = ey2 > 0 ? (float)sqrt(ey2) : 0.f;
+            if (rms > my_max) my_max = rms;          // (a NaN statistic compares false: the scale stays finite and the NaN reaches the output)
         }
     }
     if (!act_inv_scale) return;
-    gmax[threadIdx.x] = my_max;
+    for (int off = 32; off >= 1; off >>= 1) my_max = fmaxf(my_max, __shfl_xor(my_max, off));      // (a maximum: any order)
+    if ((tid & 63) == 0) gmax[tid >> 6] = my_max;
     __syncthreads();
-    float m = 0.f;
-    for (int i = 0; i < 64; ++i) m = fmaxf(m, gmax[i]);
+    const float m = fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
     int e = 0;
     float sc = 1.f, inv = 1.f;
     if (m > 0.f && m < INFINITY) {
@@ -114,19 +124,18 @@ __global__ __launch_bounds__(64) void groupnorm_affine_kernel(const double *__re
         sc = ldexpf(1.f, e);
         inv = ldexpf(1.f, -e);
     }
-    __syncthreads();
-    for (int g = threadIdx.x; g < groups; g += 64)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a[(int64_t)b * C + c] *= sc; d[(int64_t)b * C + c] *= sc; }
-    if (threadIdx.x == 0) act_inv_scale[b] = inv;
+    for (int c = tid; c < C; c += GNA_THREADS) { a[(int64_t)b * C + c] *= sc; d[(int64_t)b * C + c] *= sc; }      // (each thread rescales what it wrote)
+    if (tid == 0) act_inv_scale[b] = inv;
 }
 
 extern "C" int gn_groupnorm_affine(const double *sum0, const double *sq0, int C0, int64_t V0, const double *sum1, const double *sq1,
                                    int C1, int64_t V1, int rep1, int B, int groups, float eps, const float *gamma,
                                    const float *beta, float *a, float *d, float *act_inv_scale, void *stream) {
     GN_REQUIRE(B >= 0 && groups > 0 && C0 > 0 && C1 >= 0 && (C0 + C1) % groups == 0, "gn_groupnorm_affine: bad sizes");
+    GN_REQUIRE(C0 + C1 <= GNA_MAXC, "gn_groupnorm_affine: at most %d channels (got %d)", GNA_MAXC, C0 + C1);
     GN_REQUIRE(C1 == 0 || V1 * rep1 == V0, "gn_groupnorm_affine: source 1 must cover the same voxels after replication");
     if (B == 0) return GN_OK;
-    hipLaunchKernelGGL(groupnorm_affine_kernel, dim3((unsigned)B), dim3(64), 0, gn_stream(stream), sum0, sq0, C0, V0, sum1,
+    hipLaunchKernelGGL(groupnorm_affine_kernel, dim3((unsigned)B), dim3(GNA_THREADS), 0, gn_stream(stream), sum0, sq0, C0, V0, sum1,
                        sq1, C1, V1, rep1, B, groups, eps, gamma, beta, a, d, act_inv_scale);
     GN_LAUNCH_CHECK("gn_groupnorm_affine");
     return GN_OK;
