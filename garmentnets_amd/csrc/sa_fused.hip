@@ -231,10 +231,14 @@ __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaArgs p) {
 
 template <int CIN, int N1, int N2, int N3>
 static int sa_launch(const SaArgs &p, hipStream_t st) {
-    // enough workgroups for every CU twice over: groups of 32 centres when there are plenty, else 16 / 8
+    // enough workgroups for every CU twice over: groups of 32 centres when there are plenty, else 16 / 8; round 6: 4 / 2 for the few centres of a single
+    // garment (the second level of a batch of one: 750 centres = 94 workgroups of 8 on 256 CUs, 272 us) -- a row of the edge MLP does not depend on its
+    // tile and the maximum not on its order: the same bits for every G
     if (p.M >= 32 * 1024) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 32>), dim3((unsigned)gn_cdiv(p.M, 32)), dim3(256), 0, st, p);
     else if (p.M >= 16 * 512) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 16>), dim3((unsigned)gn_cdiv(p.M, 16)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 8>), dim3((unsigned)gn_cdiv(p.M, 8)), dim3(256), 0, st, p);
+    else if (p.M >= 8 * 256) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 8>), dim3((unsigned)gn_cdiv(p.M, 8)), dim3(256), 0, st, p);
+    else if (p.M >= 4 * 256) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 4>), dim3((unsigned)gn_cdiv(p.M, 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 2>), dim3((unsigned)gn_cdiv(p.M, 2)), dim3(256), 0, st, p);
     return 0;
 }
 
