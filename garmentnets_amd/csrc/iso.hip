@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restr
     out[t] = accum == 3 ? (float)__dsqrt_rn((double)v) : v;
 }
 
-// ---- fused form (radius <= GGM_R: sigma < 0.625, the reference's 0.5): the whole gradient magnitude of a GT x GT x 4 GT output tile in
+// ---- fused form (radius <= GGM_R: sigma < 0.625, the reference's 0.5): the whole gradient magnitude of a GGM_TZ x GGM_TY x GGM_TX (4 x 8 x 32) output tile in
 // ONE kernel -- input tile + halo staged in LDS with edge-replicated coordinates (so that every later pass is a plain correlation inside
 // the tile: replicate-at-each-pass composes), pass 0 along axis 0 with both kernels (derivative -> chain d = 0, Gaussian -> shared by
 // d = 1, 2), pass 1 along axis 1 (three chains), pass 2 along axis 2 squares and accumulates in the order d = 0, 1, 2 -- the arithmetic
@@ -97,23 +97,7 @@ __global__ __launch_bounds__(256) void ggm_correlate_kernel(const float *__restr
 #define GGM_TY 8
 #endif
 #define GGM_TX 32
-__device__ __forceinline__ float ggm_corr(const float *c, int st, const GgmWeights &gw) {
-    const int r = gw.radius;
-    double acc;
-    if (gw.symmetric == 1) {
-        acc = __dmul_rn((double)c[0], gw.w[r]);
-        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)c[j * st], (double)c[-j * st]), gw.w[r + j]));
-    } else if (gw.symmetric == -1) {
-        acc = __dmul_rn((double)c[0], gw.w[r]);
-        for (int j = -r; j < 0; ++j) acc = __dadd_rn(acc, __dmul_rn(__dsub_rn((double)c[j * st], (double)c[-j * st]), gw.w[r + j]));
-    } else {
-        acc = 0.0;
-        for (int j = -r; j <= r; ++j) acc = __dadd_rn(acc, __dmul_rn((double)c[j * st], gw.w[r + j]));
-    }
-    return (float)acc;
-}
-
-// one correlation output from a register window win[0 .. 2R] (centre at R) -- same operation order as ggm_corr; T = accumulation type
+// one correlation output from a register window win[0 .. 2R] (centre at R) -- the operation order of ggm_correlate_kernel; T = accumulation type
 template <typename T>
 __device__ __forceinline__ float ggm_corr_win(const float *win, const GgmW<T> &gw) {
     constexpr int R = GGM_R;
@@ -237,7 +221,7 @@ __global__ __launch_bounds__(256) void ggm_fused_kernel(const float *__restrict_
         }
     }
     __syncthreads();
-    // pass 2 (axis 2): squares accumulated in the order d = 0, 1, 2 (fp32), correctly rounded square root.  lane = one of the 64 (z, y) rows,
+    // pass 2 (axis 2): squares accumulated in the order d = 0, 1, 2 (fp32), correctly rounded square root.  thread = one of the TZ x TY (z, y) rows x one x chunk,
     // wave = an 8-wide x chunk (conflict-free LDS reads thanks to the odd row pitch); the results go through LDS (the dead B region) so
     // that the global stores are rows of 32 consecutive x
     float *const O = B;
