@@ -1035,9 +1035,12 @@ __device__ __forceinline__ void mc_attr_one(const float *__restrict__ vol, const
     values[vid] = val;
 }
 
-// normals / values: one thread per vertex (4 per thread, strided), the vertex's edge slot read back from its normal row; the gather visits
-// the (<= 4) cells that share the edge in sweep order -- they are all crossed by the surface, so classify has written their tiling rows
-#define MC_ATTR_PER_WG 1024
+// normals / values: one thread per vertex, the vertex's edge slot read back from its normal row; the gather visits the (<= 4) cells that share the edge in
+// sweep order -- they are all crossed by the surface, so classify has written their tiling rows.  (Round 6: 256 instead of 1024 vertices per workgroup -- a
+// vertex is one long dependent chain of fp64 gathers, four of them back to back per thread left a single garment's 38 000 vertices on 38 workgroups: 79 us.)
+#ifndef MC_ATTR_PER_WG
+#define MC_ATTR_PER_WG 256
+#endif
 __global__ __launch_bounds__(256) void mc_attrs_kernel(const float *__restrict__ vol, McDims d, double level, const int32_t *__restrict__ cinfo,
                                                        const int64_t *__restrict__ counts_dev, float *__restrict__ normals, float *__restrict__ values,
                                                        int64_t cap_v) {
