@@ -47,15 +47,27 @@ __global__ void cprep_scales_kernel(const double *__restrict__ sum, const double
 // -> cls = (mz * 4 + my) * 4 + mx (64 entries; 63 = interior)
 // WINO: the row maximum is taken over the Winograd F(2,3)-along-x transformed weights (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2 per (kd, kh, channel)):
 // that is what the fp16 planes of the Winograd pack hold (unet_wino.hip)
+#define CPREP_ROW_LDS (128 * 27)
 template <bool WINO>
 __global__ __launch_bounds__(64) void cprep_rows_kernel(const float *__restrict__ w, const float *__restrict__ wfac, const double *__restrict__ mconst,
                                                         int Cin, int Cout, float *__restrict__ rowscale, float *__restrict__ osc, float *__restrict__ kbias) {
     const int n = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     __shared__ double tsum[27];
     __shared__ float tmax[64];
+    // round 6: the output channel's weight row is staged in LDS once (coalesced) when it fits -- the 27 per-tap sums below walk it channel by channel in a fixed
+    // order (fp64, order-sensitive: kept), and did so through 128 dependent global loads: 17 - 24 us per launch for a few KB of work
+    __shared__ float wrow[CPREP_ROW_LDS];
     const float *wr = w + (int64_t)n * Cin * 27;
     const float *f = wfac + (int64_t)b * Cin;
     const double *m = mconst + (int64_t)b * Cin;
+    __shared__ double mrow[CPREP_ROW_LDS / 27];
+    if (Cin * 27 <= CPREP_ROW_LDS) {
+        for (int i = lane; i < Cin * 27; i += 64) wrow[i] = wr[i];
+        for (int i = lane; i < Cin; i += 64) mrow[i] = m[i];
+        __syncthreads();
+        wr = wrow;
+        m = mrow;
+    }
     float mx = 0.f;
     if (WINO) {
         for (int i = lane; i < Cin * 9; i += 64) {
