@@ -229,16 +229,44 @@ __global__ __launch_bounds__(256, 2) void sa_fused_kernel(SaArgs p) {
     }
 }
 
+// centres per workgroup.  A row of the edge MLP does not depend on its tile and the maximum not on its order: every G gives the same bits, so G is free to follow
+// the launch geometry (round 6): cost(G) = (2 G + 1) / (2 G)  [the self-loop tile's share]  /  fill of the last round of resident workgroups -- 12 000 second-level
+// centres of a batch of 16 in groups of 16 were 750 workgroups on 512 slots (1.46 rounds), in groups of 8 they are 2.93; 750 centres of one garment in groups of
+// 8 were 94 workgroups on 256 CUs.  Resident workgroups per CU from the runtime's occupancy query, once per instantiation.
+template <int CIN, int N1, int N2, int N3, int G>
+static int sa_slots() {
+    static const int slots = [] {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)sa_fused_kernel<CIN, N1, N2, N3, G>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        return per_cu * cus;
+    }();
+    return slots;
+}
+template <int CIN, int N1, int N2, int N3, int G>
+static double sa_cost(int M) {
+    const double n = (double)gn_cdiv(M, G), slots = (double)sa_slots<CIN, N1, N2, N3, G>();
+    const double rounds = (double)gn_cdiv((int64_t)n, (int64_t)slots);
+    return (2.0 * G + 1.0) / (2.0 * G) * rounds * slots / n;
+}
 template <int CIN, int N1, int N2, int N3>
 static int sa_launch(const SaArgs &p, hipStream_t st) {
-    // enough workgroups for every CU twice over: groups of 32 centres when there are plenty, else 16 / 8; round 6: 4 / 2 for the few centres of a single
-    // garment (the second level of a batch of one: 750 centres = 94 workgroups of 8 on 256 CUs, 272 us) -- a row of the edge MLP does not depend on its
-    // tile and the maximum not on its order: the same bits for every G
-    if (p.M >= 32 * 1024) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 32>), dim3((unsigned)gn_cdiv(p.M, 32)), dim3(256), 0, st, p);
-    else if (p.M >= 16 * 512) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 16>), dim3((unsigned)gn_cdiv(p.M, 16)), dim3(256), 0, st, p);
-    else if (p.M >= 8 * 256) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 8>), dim3((unsigned)gn_cdiv(p.M, 8)), dim3(256), 0, st, p);
-    else if (p.M >= 4 * 256) hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 4>), dim3((unsigned)gn_cdiv(p.M, 4)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 2>), dim3((unsigned)gn_cdiv(p.M, 2)), dim3(256), 0, st, p);
+    const double c32 = sa_cost<CIN, N1, N2, N3, 32>(p.M), c16 = sa_cost<CIN, N1, N2, N3, 16>(p.M), c8 = sa_cost<CIN, N1, N2, N3, 8>(p.M),
+                 c4 = sa_cost<CIN, N1, N2, N3, 4>(p.M), c2 = sa_cost<CIN, N1, N2, N3, 2>(p.M);
+    double best = c32;                              // ties go to the larger group (fewer weight re-reads)
+    int g = 32;
+    if (c16 < best) { best = c16; g = 16; }
+    if (c8 < best) { best = c8; g = 8; }
+    if (c4 < best) { best = c4; g = 4; }
+    if (c2 < best) { best = c2; g = 2; }
+    switch (g) {
+        case 32: hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 32>), dim3((unsigned)gn_cdiv(p.M, 32)), dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 16>), dim3((unsigned)gn_cdiv(p.M, 16)), dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 8>), dim3((unsigned)gn_cdiv(p.M, 8)), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 4>), dim3((unsigned)gn_cdiv(p.M, 4)), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((sa_fused_kernel<CIN, N1, N2, N3, 2>), dim3((unsigned)gn_cdiv(p.M, 2)), dim3(256), 0, st, p); break;
+    }
     return 0;
 }
 
